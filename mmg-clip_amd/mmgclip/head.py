@@ -1,0 +1,178 @@
+"""Host side of the contrastive head: autograd wrappers over the fp32 gfx950 kernels of csrc/clip_head.hip.
+
+Reference arithmetic (path:line in the reference tree):
+    mmgclip/networks/mmgclip_model.py:128-136  normalise, exp(logit_scale), two logit matmuls
+    mmgclip/loss/losses.py:36-44               CLIPLoss
+PyTorch is used for allocation / stream / autograd plumbing only; every FLOP below runs in the HIP library.
+"""
+import torch
+
+from . import _hip
+from ._hip import call, ptr, stream
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class L2Normalize(torch.autograd.Function):
+    """y = x / ||x||_2 per row (no epsilon) — mmgclip_model.py:128-129."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _hip.require_gpu(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        norm = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        call("mmg_l2norm_fwd", ptr(x), ptr(y), ptr(norm), x.shape[0], x.shape[1], stream())
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, norm = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(y)
+        call("mmg_l2norm_bwd", ptr(y), ptr(norm), ptr(dy), ptr(dx), y.shape[0], y.shape[1], stream())
+        return dx
+
+
+def rows_forward(x_loc, y_all, scale, diag_off=0, want_logits=False):
+    """lse, pos (and logits) of s * x_loc @ y_all.T — one launch, no autograd."""
+    n_loc, D = x_loc.shape
+    N = y_all.shape[0]
+    lse = torch.empty(n_loc, device=x_loc.device, dtype=torch.float32)
+    pos = torch.empty(n_loc, device=x_loc.device, dtype=torch.float32)
+    logits = torch.empty(n_loc, N, device=x_loc.device, dtype=torch.float32) if want_logits else None
+    call("mmg_clip_rows_fwd", ptr(x_loc), ptr(y_all), ptr(scale), n_loc, N, D, diag_off, ptr(lse), ptr(pos),
+         ptr(logits), N if want_logits else 0, stream())
+    return lse, pos, logits
+
+
+class ScaledLogits(torch.autograd.Function):
+    """logits_per_image, logits_per_text = s * I @ T.t(), s * T @ I.t()  (mmgclip_model.py:135-136).
+
+    Materialises both [n,n] matrices because the reference API returns them; the backward takes arbitrary
+    upstream gradients of both (mmg_clip_rows_bwd_dense).
+    """
+
+    @staticmethod
+    def forward(ctx, img, txt, scale):
+        _hip.require_gpu(img, txt, scale)
+        img, txt = _f32c(img), _f32c(txt)
+        scale = _f32c(scale.reshape(1))
+        _, _, li = rows_forward(img, txt, scale, 0, True)
+        _, _, lt = rows_forward(txt, img, scale, 0, True)
+        ctx.save_for_backward(img, txt, scale)
+        return li, lt
+
+    @staticmethod
+    def backward(ctx, dli, dlt):
+        img, txt, scale = ctx.saved_tensors
+        n, D = img.shape
+        dli = _f32c(dli) if dli is not None else None
+        dlt = _f32c(dlt) if dlt is not None else None
+        dimg = torch.empty_like(img)
+        dtxt = torch.empty_like(txt)
+        dscale = torch.zeros(1, device=img.device, dtype=torch.float32)
+        # d img = s (dLi + dLt^T) T ; d txt = s (dLt + dLi^T) I ; ds counted once (first call)
+        call("mmg_clip_rows_bwd_dense", ptr(img), ptr(txt), ptr(scale), ptr(dli), n, ptr(dlt), n, n, n, D,
+             ptr(dimg), ptr(dscale), stream())
+        call("mmg_clip_rows_bwd_dense", ptr(txt), ptr(img), ptr(scale), ptr(dlt), n, ptr(dli), n, n, n, D,
+             ptr(dtxt), None, stream())
+        return dimg, dtxt, dscale.reshape(())
+
+
+class CrossEntropyRows(torch.autograd.Function):
+    """mean_r ( logsumexp(z_r) - z_r[label_r] ) * weight — F.cross_entropy of losses.py:40-41 on device."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight):
+        _hip.require_gpu(logits)
+        logits = _f32c(logits)
+        rows, C = logits.shape
+        if labels is not None:
+            labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+        lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
+        loss = torch.zeros(1, device=logits.device, dtype=torch.float32)
+        w = float(weight) / rows
+        call("mmg_ce_rows_fwd", ptr(logits), C, ptr(labels), rows, C, w, ptr(lse), ptr(loss), stream())
+        ctx.save_for_backward(logits, lse, labels if labels is not None else torch.empty(0))
+        ctx.has_labels = labels is not None
+        ctx.w = w
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, lse, labels = ctx.saved_tensors
+        rows, C = logits.shape
+        gout = _f32c(gout.reshape(1))
+        d = torch.empty_like(logits)
+        call("mmg_ce_rows_bwd", ptr(logits), C, ptr(labels) if ctx.has_labels else None, ptr(lse), ptr(gout),
+             ctx.w, rows, C, ptr(d), C, stream())
+        return d, None, None
+
+
+def cross_entropy(logits, labels=None, weight=1.0):
+    return CrossEntropyRows.apply(logits, labels, weight)
+
+
+class FusedClipLoss(torch.autograd.Function):
+    """CLIPLoss over (already L2-normalised) embeddings without materialising logits.
+
+    loss = 1/(2N) [ sum_i (lse_i(A) - A_ii) + sum_j (lse_j(A^T) - A_jj) ],  A = s I T^T   (losses.py:36-44)
+
+    With a process group the columns are the all-gathered embeddings of every rank: exchange 1
+    gathers the normalised embeddings, exchange 2 the two log-sum-exp vectors; gradients w.r.t. the local
+    embeddings are then complete locally (no reduce-scatter).  `group=None` is the reference's local-batch loss.
+    The returned loss is the GLOBAL mean (identical on every rank); gradients are d(global loss)/d(local rows),
+    so parameter gradients must be SUMMED across ranks (mmgclip/distributed.py does that).
+    """
+
+    @staticmethod
+    def forward(ctx, img, txt, scale, comm):
+        _hip.require_gpu(img, txt, scale)
+        img, txt = _f32c(img), _f32c(txt)
+        scale = _f32c(scale.reshape(1))
+        n_loc, D = img.shape
+        if comm is None or comm.world_size == 1:
+            img_all, txt_all, off, N = img, txt, 0, n_loc
+        else:
+            img_all, txt_all = comm.all_gather_rows(img), comm.all_gather_rows(txt)
+            off, N = comm.rank * n_loc, n_loc * comm.world_size
+        lse_i, pos_i, _ = rows_forward(img, txt_all, scale, off)
+        lse_t, pos_t, _ = rows_forward(txt, img_all, scale, off)
+        loss = torch.zeros(1, device=img.device, dtype=torch.float32)
+        call("mmg_clip_loss_reduce", ptr(lse_i), ptr(pos_i), ptr(lse_t), ptr(pos_t), n_loc, 1.0 / (2.0 * N),
+             ptr(loss), stream())
+        if comm is not None and comm.world_size > 1:
+            lse_i_all, lse_t_all = comm.all_gather_rows(lse_i), comm.all_gather_rows(lse_t)
+            loss = comm.all_reduce_sum(loss)
+        else:
+            lse_i_all, lse_t_all = lse_i, lse_t
+        ctx.save_for_backward(img, txt, scale, img_all, txt_all, lse_i, lse_t, lse_i_all, lse_t_all)
+        ctx.off, ctx.N = off, N
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        img, txt, scale, img_all, txt_all, lse_i, lse_t, lse_i_all, lse_t_all = ctx.saved_tensors
+        n_loc, D = img.shape
+        N, off = ctx.N, ctx.off
+        gout = _f32c(gout.reshape(1))
+        dimg = torch.empty_like(img)
+        dtxt = torch.empty_like(txt)
+        dscale = torch.zeros(1, device=img.device, dtype=torch.float32)
+        coef = 1.0 / (2.0 * N)
+        call("mmg_clip_rows_bwd_fused", ptr(img), ptr(txt_all), ptr(scale), ptr(lse_i), ptr(lse_t_all), ptr(gout),
+             coef, n_loc, N, D, off, ptr(dimg), ptr(dscale), stream())
+        call("mmg_clip_rows_bwd_fused", ptr(txt), ptr(img_all), ptr(scale), ptr(lse_t), ptr(lse_i_all), ptr(gout),
+             coef, n_loc, N, D, off, ptr(dtxt), None, stream())
+        return dimg, dtxt, dscale.reshape(()), None
+
+
+def fused_clip_loss(image_embeddings, text_embeddings, logit_scale, comm=None):
+    """CLIPLoss on normalised embeddings; `logit_scale` is the already exponentiated scale (a tensor)."""
+    return FusedClipLoss.apply(image_embeddings, text_embeddings, logit_scale, comm)
