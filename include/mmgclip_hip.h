@@ -80,6 +80,29 @@ int mmg_ce_rows_bwd(const float* logits, int ld, const long long* labels, const 
 int mmg_clip_loss_reduce(const float* lse_a, const float* pos_a, const float* lse_b, const float* pos_b, int n,
                          float coef, float* loss, mmg_stream_t stream);
 
+/* ---- bf16 MFMA GEMMs (encoder towers, projection heads) -------------------------------------------------- */
+
+/* C[M,N] = epilogue( alpha * A[M,K] B[N,K]^T + bias )   A,B bf16 row-major (K contiguous), fp32 accumulate.
+ * epilogue (in this order): + bias[N];  activation by `epi`:
+ *     0 none | 1 GELU(erf) (aux_out, when given, receives the pre-activation) | 2 multiply by GELU'(aux_in)
+ *     3 ReLU (aux_out as 1)  | 4 ReLU' (gate by aux_in > 0);
+ * then * colscale[N] (ConvNeXt layer scale), + residual[M,N] (bf16); C is bf16 (out_f32 = 0) or fp32.
+ * K % 32 == 0, N % 8 == 0, leading dimensions multiples of 8.
+ * Replaces nn.Linear forward / data-gradient in HF BertLayer (reference call site mmgclip/networks/encoder.py:156),
+ * torchvision CNBlock + patchify convs (mmgclip/networks/encoder.py:53, mmgclip/networks/image_features.py:100)
+ * and the projection heads (mmgclip/networks/projection.py:33,55-61,94-101). */
+int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     const float* bias, const float* colscale, const void* residual, int ldr, const void* aux_in,
+                     int ldai, void* aux_out, int ldao, int epi, int out_f32, float alpha, mmg_stream_t stream);
+
+/* Weight gradient: C[N1,N2] += alpha * A[M,N1]^T B[M,N2]  (A,B bf16; C fp32, accumulated with atomics, so the
+ * caller zeroes C once per optimisation step).  Autograd of the linears above w.r.t. their weights. */
+int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+                     float alpha, mmg_stream_t stream);
+
+/* Bias gradient: out[n] += sum_m A[m,n]  (A bf16 [M,N]). */
+int mmg_colsum_bf16(const void* A, int lda, int M, int N, float* out, mmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

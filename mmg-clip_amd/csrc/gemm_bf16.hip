@@ -1,0 +1,446 @@
+// bf16 MFMA GEMMs for the encoder towers (gfx950).
+//
+//   mmg_gemm_nt_bf16 : C[M,N]   = epilogue( A[M,K] * B[N,K]^T )          forward linears, data gradients
+//   mmg_gemm_tn_bf16 : C[N1,N2] += A[M,N1]^T * B[M,N2]   (fp32, atomic)  weight gradients
+//
+// These replace the ATen/cuBLAS calls behind nn.Linear in the reference's towers:
+//   HF BertLayer Q/K/V/out/FFN linears  (mmgclip/networks/encoder.py:138,156),
+//   torchvision CNBlock Linear(C,4C)/Linear(4C,C) and the 2x2/4x4 patchify convolutions of ConvNeXt
+//   (mmgclip/networks/encoder.py:53; module tree in notebooks/clf_convnext_tiny_experimental.ipynb cell 3),
+//   nn.Linear of the projection heads (mmgclip/networks/projection.py:17,42-49,88-90).
+//
+// Design (CDNA4): 256 threads = 4 waves as 2x2, v_mfma_f32_16x16x32_bf16, operands staged HBM -> LDS with
+// 16-byte global_load_lds (no VGPR round trip), double-buffered, one barrier per K tile.  The LDS image is
+// lane-linear (a requirement of LDS-DMA), so the bank-conflict swizzle is applied to the per-lane SOURCE
+// address and again on the fragment read (an XOR involution).  The MFMA is issued swapped (A := weight
+// fragment, B := activation fragment) so a lane ends up with 4 CONSECUTIVE output columns of one row; the
+// accumulators go through LDS once and leave as whole 16-byte row segments with bias / GELU / layer-scale /
+// residual applied on the way (no separate elementwise kernels, no fp32 round trip through HBM).
+// The weight-gradient kernel reads both operands with ds_read_b64_tr_b16 (hardware transpose) because the
+// reduction index (the row m) is the slow index of both inputs.
+#include "common.h"
+
+#define GEMM_THREADS 256
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RELU = 3, EPI_DRELU = 4 };
+
+struct GemmNT {
+    const bf16_t* A; const bf16_t* B;
+    int M, N, K, lda, ldb;
+    void* C; int ldc; int out_f32;
+    const float* bias;        // [N]  added to the accumulator
+    const float* colscale;    // [N]  multiplies after activation (ConvNeXt layer scale)
+    const bf16_t* residual; int ldr;   // [M,N] added last
+    const bf16_t* aux_in; int ldai;    // [M,N] pre-activation for EPI_DGELU / EPI_DRELU
+    bf16_t* aux_out; int ldao;         // [M,N] receives the pre-activation for EPI_GELU / EPI_RELU (may be null)
+    int epi;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XOR applied to the 16-byte chunk index of row r (see the bank analysis in DESIGN.md §kernels/GEMM)
+template <int BK>
+__device__ __forceinline__ int swz(int r) {
+    if (BK == 64) return r & 7;
+    return (4 - ((r >> 2) & 3)) & 3;   // BK == 32
+}
+
+// Stage ROWS x BK bf16 (rows row0.. of G, clamped to rows_total-1) into a lane-linear LDS tile.
+template <int ROWS, int BK>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ G, int ld, int row0, int rows_total, int k0,
+                                           char* lds_tile, int tid) {
+    constexpr int CPR = BK / 8;
+    constexpr int NCH = ROWS * CPR;
+#pragma unroll
+    for (int it = 0; it < (NCH + GEMM_THREADS - 1) / GEMM_THREADS; ++it) {
+        const int p = it * GEMM_THREADS + tid;
+        if (NCH % GEMM_THREADS == 0 || p < NCH) {
+            const int r = p / CPR, s = p % CPR;
+            const int c = s ^ swz<BK>(r);
+            const int gr = min(row0 + r, rows_total - 1);
+            glds16(G + (size_t)gr * ld + k0 + c * 8, lds_tile + (size_t)(it * GEMM_THREADS + (tid & ~63)) * 16);
+        }
+    }
+}
+
+template <int BK>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int r, int c) {
+    return *reinterpret_cast<const bf16x8*>(lds_tile + r * (BK * 2) + ((c ^ swz<BK>(r)) << 4));
+}
+
+// XCD-aware tile order: workgroups that share an A row panel run on one XCD (same L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, l = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmNT g) {
+    constexpr int MI = BM / 32, NI = BN / 32;      // 16x16 fragments per wave (wave tile = BM/2 x BN/2)
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int LDCS = BN + 4;                    // fp32 staging pitch
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // stage s: A tile at s*(A_BYTES+B_BYTES), B tile right behind it
+#define NT_AS(s) (smem + (s) * (A_BYTES + B_BYTES))
+#define NT_BS(s) (smem + (s) * (A_BYTES + B_BYTES) + A_BYTES)
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage_rows<BM, BK>(g.A, g.lda, m0, g.M, 0, NT_AS(0), tid);
+    stage_rows<BN, BK>(g.B, g.ldb, n0, g.N, 0, NT_BS(0), tid);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            stage_rows<BM, BK>(g.A, g.lda, m0, g.M, (kt + 1) * BK, NT_AS(cur ^ 1), tid);
+            stage_rows<BN, BK>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, NT_BS(cur ^ 1), tid);
+        }
+        const char* a_t = NT_AS(cur);
+        const char* b_t = NT_BS(cur);
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = read_frag<BK>(a_t, wm * (BM / 2) + i * 16 + li, 4 * ks + lg);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = read_frag<BK>(b_t, wn * (BN / 2) + j * 16 + li, 4 * ks + lg);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // all fragment reads done before the staging buffers become the C tile
+
+    // accumulators -> LDS (row = m, 4 consecutive n per lane)
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int r = wm * (BM / 2) + i * 16 + li;
+            const int c = wn * (BN / 2) + j * 16 + 4 * lg;
+            *reinterpret_cast<f32x4*>(Cs + r * LDCS + c) = acc[i][j];
+        }
+    __syncthreads();
+
+    // coalesced epilogue: each thread owns 8 consecutive columns of a row
+    constexpr int TPR = BN / 8;                       // threads per row
+    constexpr int RPP = GEMM_THREADS / TPR;           // rows per pass
+    const int tr = tid / TPR, tc = (tid % TPR) * 8;
+    const int gc = n0 + tc;
+    if (tr < RPP && gc < g.N) {
+        float bias[8], cs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bias[e] = g.bias ? g.bias[gc + e] : 0.f;
+            cs[e] = g.colscale ? g.colscale[gc + e] : 1.f;
+        }
+        for (int r = tr; r < BM; r += RPP) {
+            const int gr = m0 + r;
+            if (gr >= g.M) break;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDCS + tc);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDCS + tc + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bias[e];
+            if (g.epi == EPI_GELU || g.epi == EPI_RELU) {
+                if (g.aux_out) {
+                    uint4 o;
+                    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+                    *reinterpret_cast<uint4*>(g.aux_out + (size_t)gr * g.ldao + gc) = o;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
+            } else if (g.epi == EPI_DGELU || g.epi == EPI_DRELU) {
+                const uint4 h = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
+                const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
+                    if (g.epi == EPI_DGELU) {
+                        v[2 * e] *= gelu_grad_f(h0);
+                        v[2 * e + 1] *= gelu_grad_f(h1);
+                    } else {
+                        v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;
+                        v[2 * e + 1] = h1 > 0.f ? v[2 * e + 1] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= cs[e];
+            if (g.residual) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
+                const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
+            }
+            if (g.out_f32) {
+                float* dst = reinterpret_cast<float*>(g.C) + (size_t)gr * g.ldc + gc;
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                uint4 o;
+                o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (size_t)gr * g.ldc + gc) = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK>
+static void launch_nt(GemmNT& g, hipStream_t stream) {
+    g.tiles_m = cdiv(g.M, BM);
+    g.tiles_n = cdiv(g.N, BN);
+    const size_t stage = 2 * (size_t)(BM * BK * 2 + BN * BK * 2);
+    const size_t cs = (size_t)BM * (BN + 4) * 4;
+    const size_t shm = stage > cs ? stage : cs;
+    mmg_allow_lds(gemm_nt_kernel<BM, BN, BK>, shm);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK>), dim3(g.tiles_m * g.tiles_n), dim3(GEMM_THREADS), shm, stream, g);
+}
+
+MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                             const float* bias, const float* colscale, const void* residual, int ldr,
+                             const void* aux_in, int ldai, void* aux_out, int ldao, int epi, int out_f32, float alpha,
+                             hipStream_t stream) {
+    MMG_CHECK_ARG(A && B && C, "mmg_gemm_nt_bf16: null operand");
+    MMG_CHECK_ARG(M > 0 && N > 0 && K > 0, "mmg_gemm_nt_bf16: M=%d N=%d K=%d must be positive", M, N, K);
+    MMG_CHECK_ARG(K % 32 == 0, "mmg_gemm_nt_bf16: K=%d must be a multiple of 32", K);
+    MMG_CHECK_ARG(N % 8 == 0, "mmg_gemm_nt_bf16: N=%d must be a multiple of 8", N);
+    MMG_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0,
+                  "mmg_gemm_nt_bf16: leading dimensions must cover the row and be multiples of 8 (lda=%d ldb=%d ldc=%d)",
+                  lda, ldb, ldc);
+    MMG_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_DRELU, "mmg_gemm_nt_bf16: unknown epilogue %d", epi);
+    MMG_CHECK_ARG(!(epi == EPI_DGELU || epi == EPI_DRELU) || (aux_in && ldai >= N && ldai % 8 == 0),
+                  "mmg_gemm_nt_bf16: activation-gradient epilogue needs aux_in");
+    MMG_CHECK_ARG(!residual || (ldr >= N && ldr % 8 == 0), "mmg_gemm_nt_bf16: bad ldr=%d", ldr);
+    MMG_CHECK_ARG(!aux_out || (ldao >= N && ldao % 8 == 0), "mmg_gemm_nt_bf16: bad ldao=%d", ldao);
+    GemmNT g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.bias = bias; g.colscale = colscale;
+    g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = (const bf16_t*)aux_in; g.ldai = ldai;
+    g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha;
+    const bool k64 = (K % 64 == 0);
+    // N tile: 96 when it divides N and 128 does not (ConvNeXt widths 96/192), else 128
+    const bool n96 = (N % 128 != 0) && (N % 96 == 0);
+    if (n96) { if (k64) launch_nt<128, 96, 64>(g, stream); else launch_nt<128, 96, 32>(g, stream); }
+    else     { if (k64) launch_nt<128, 128, 64>(g, stream); else launch_nt<128, 128, 32>(g, stream); }
+    MMG_LAUNCH_CHECK("mmg_gemm_nt_bf16");
+    return 0;
+}
+
+// =============================================================================================
+// TN (weight gradient): C[N1,N2] += A[M,N1]^T B[M,N2], fp32 atomics, reduction split over workgroups
+// =============================================================================================
+struct GemmTN {
+    const bf16_t* A; const bf16_t* B;
+    int M, N1, N2, lda, ldb;
+    float* C; int ldc;
+    int tiles1, tiles2, rows_per_chunk;
+    float alpha;
+};
+
+#define TN_T 128     // output tile edge
+#define TN_BK 64     // reduction rows per stage
+
+// physical 16-byte chunk of logical chunk c in reduction row m (row = 256 B = one LDS bank row)
+__device__ __forceinline__ int tn_swz(int m, int c) {
+    const int f = (m & 3) | (((m >> 3) & 1) << 2);
+    return (((c >> 1) ^ f) << 1) | (c & 1);
+}
+
+// rows m (reduction) x 128 columns (col0.., clamped) -> lane-linear LDS tile, swizzled on the source side
+__device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ G, int ld, int m0, int M, int col0, int ncols,
+                                         char* lds_tile, int tid) {
+#pragma unroll
+    for (int it = 0; it < (TN_BK * 16) / GEMM_THREADS; ++it) {
+        const int p = it * GEMM_THREADS + tid;
+        const int r = p >> 4, s = p & 15;
+        // tn_swz is an involution in c for fixed m: logical chunk stored at physical slot s
+        const int c = tn_swz(r, s);
+        const int gm = min(m0 + r, M - 1);
+        const int gc = min(col0 + c * 8, ncols - 8);
+        glds16(G + (size_t)gm * ld + gc, lds_tile + (size_t)(it * GEMM_THREADS + (tid & ~63)) * 16);
+    }
+}
+
+// transposed fragment of a 16-column block: lane (i, g) receives tile[mk + 8g + 0..7][cb*16 + i]
+__device__ __forceinline__ bf16x8 read_frag_tr(const char* lds_tile, int mk, int cb, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int m_a = mk + 8 * g + q, m_b = m_a + 4;
+    const int c = cb * 2 + (p >> 1);   // logical 16-byte chunk holding columns cb*16 + 4p .. 4p+3
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const char* pa = lds_tile + m_a * 256 + tn_swz(m_a, c) * 16 + (p & 1) * 8;
+    const char* pb = lds_tile + m_b * 256 + tn_swz(m_b, c) * 16 + (p & 1) * 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pb);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const GemmTN g) {
+    constexpr int TILE_BYTES = TN_BK * TN_T * 2;   // 16 KiB
+    constexpr int LDCS = TN_T + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#define TN_AS(s) (smem + (s) * 2 * TILE_BYTES)
+#define TN_BS(s) (smem + (s) * 2 * TILE_BYTES + TILE_BYTES)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int w1 = wave >> 1, w2 = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int tile = blockIdx.x, chunk = blockIdx.y;
+    const int t1 = tile / g.tiles2, t2 = tile - t1 * g.tiles2;
+    const int c1 = t1 * TN_T, c2 = t2 * TN_T;
+    const int m_begin = chunk * g.rows_per_chunk;
+    const int m_end = min(m_begin + g.rows_per_chunk, g.M);
+    if (m_begin >= m_end) return;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (m_end - m_begin + TN_BK - 1) / TN_BK;
+    stage_tn(g.A, g.lda, m_begin, g.M, c1, g.N1, TN_AS(0), tid);
+    stage_tn(g.B, g.ldb, m_begin, g.M, c2, g.N2, TN_BS(0), tid);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        const int mt = m_begin + kt * TN_BK;
+        if (mt + TN_BK > m_end) {
+            // ragged end of the reduction: rows >= m_end must contribute zero (they hold clamped duplicates)
+            const int valid = m_end - mt;
+            for (int p = tid; p < (TN_BK - valid) * 16; p += GEMM_THREADS) {
+                const int r = valid + (p >> 4), s = p & 15;
+                *reinterpret_cast<uint4*>(TN_AS(cur) + r * 256 + s * 16) = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(TN_BS(cur) + r * 256 + s * 16) = make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        if (kt + 1 < nk) {
+            stage_tn(g.A, g.lda, mt + TN_BK, g.M, c1, g.N1, TN_AS(cur ^ 1), tid);
+            stage_tn(g.B, g.ldb, mt + TN_BK, g.M, c2, g.N2, TN_BS(cur ^ 1), tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < TN_BK / 32; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag_tr(TN_AS(cur), ks * 32, w1 * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = read_frag_tr(TN_BS(cur), ks * 32, w2 * 4 + j, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // swapped issue: lane (li, lg) holds C[n1 = .. + li][n2 = .. + 4 lg + 0..3]
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = w1 * 64 + i * 16 + li;
+            const int c = w2 * 64 + j * 16 + 4 * lg;
+            *reinterpret_cast<f32x4*>(Cs + r * LDCS + c) = acc[i][j];
+        }
+    __syncthreads();
+    // 256-byte contiguous atomic rows (one wave instruction = 64 consecutive floats)
+    for (int idx = tid; idx < TN_T * TN_T; idx += GEMM_THREADS) {
+        const int r = idx >> 7, c = idx & 127;
+        const int gr = c1 + r, gc = c2 + c;
+        if (gr < g.N1 && gc < g.N2) atomicAdd(g.C + (size_t)gr * g.ldc + gc, Cs[r * LDCS + c] * g.alpha);
+    }
+}
+
+MMG_API int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+                             float alpha, hipStream_t stream) {
+    MMG_CHECK_ARG(A && B && C, "mmg_gemm_tn_bf16: null operand");
+    MMG_CHECK_ARG(M > 0 && N1 >= 8 && N2 >= 8, "mmg_gemm_tn_bf16: M=%d N1=%d N2=%d", M, N1, N2);
+    MMG_CHECK_ARG(N1 % 8 == 0 && N2 % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= N1 && ldb >= N2 && ldc >= N2,
+                  "mmg_gemm_tn_bf16: N1=%d N2=%d lda=%d ldb=%d ldc=%d must be multiples of 8 and consistent", N1, N2,
+                  lda, ldb, ldc);
+    GemmTN g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N1 = N1; g.N2 = N2; g.lda = lda; g.ldb = ldb;
+    g.C = C; g.ldc = ldc; g.alpha = alpha;
+    g.tiles1 = cdiv(N1, TN_T);
+    g.tiles2 = cdiv(N2, TN_T);
+    const int tiles = g.tiles1 * g.tiles2;
+    int chunks = 1024 / tiles;
+    if (chunks < 1) chunks = 1;
+    const int max_chunks = cdiv(M, TN_BK);
+    if (chunks > max_chunks) chunks = max_chunks;
+    g.rows_per_chunk = cdiv(cdiv(M, chunks), TN_BK) * TN_BK;
+    chunks = cdiv(M, g.rows_per_chunk);
+    const size_t stage = 4 * (size_t)(TN_BK * TN_T * 2);
+    const size_t cs = (size_t)TN_T * (TN_T + 4) * 4;
+    const size_t shm = stage > cs ? stage : cs;
+    mmg_allow_lds(gemm_tn_kernel, shm);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks), dim3(GEMM_THREADS), shm, stream, g);
+    MMG_LAUNCH_CHECK("mmg_gemm_tn_bf16");
+    return 0;
+}
+
+// =============================================================================================
+// column sums of a bf16 matrix (bias gradients): out[n] += sum_m A[m,n]
+// =============================================================================================
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ A, int lda, int M, int N,
+                                                     int rows_per_block, float* __restrict__ out) {
+    extern __shared__ float sums[];   // [N]
+    for (int i = threadIdx.x; i < N; i += 256) sums[i] = 0.f;
+    __syncthreads();
+    const int ng = N / 8;                       // 16-byte column groups
+    const int lanes_r = 256 / ng > 0 ? 256 / ng : 1;
+    const int m_begin = blockIdx.x * rows_per_block, m_end = min(m_begin + rows_per_block, M);
+    for (int cg0 = 0; cg0 < ng; cg0 += 256) {
+        const int cg = cg0 + (threadIdx.x % (ng < 256 ? ng : 256));
+        const int rl = threadIdx.x / (ng < 256 ? ng : 256);
+        if (cg < ng && rl < lanes_r) {
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int m = m_begin + rl; m < m_end; m += lanes_r) {
+                const uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)m * lda + cg * 8);
+                s[0] += bf2f_lo(v.x); s[1] += bf2f_hi(v.x); s[2] += bf2f_lo(v.y); s[3] += bf2f_hi(v.y);
+                s[4] += bf2f_lo(v.z); s[5] += bf2f_hi(v.z); s[6] += bf2f_lo(v.w); s[7] += bf2f_hi(v.w);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&sums[cg * 8 + e], s[e]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) atomicAdd(out + i, sums[i]);
+}
+
+MMG_API int mmg_colsum_bf16(const void* A, int lda, int M, int N, float* out, hipStream_t stream) {
+    MMG_CHECK_ARG(A && out && M > 0 && N > 0 && N % 8 == 0 && lda % 8 == 0 && lda >= N && N <= 8192,
+                  "mmg_colsum_bf16: bad argument (M=%d N=%d lda=%d)", M, N, lda);
+    int blocks = cdiv(M, 256);
+    if (blocks > 2048) blocks = 2048;
+    const int rpb = cdiv(M, blocks);
+    blocks = cdiv(M, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), N * sizeof(float), stream, (const bf16_t*)A, lda, M, N, rpb, out);
+    MMG_LAUNCH_CHECK("mmg_colsum_bf16");
+    return 0;
+}

@@ -1,0 +1,442 @@
+// HBM-bound kernels of the encoder towers (gfx950): LayerNorm fwd/bwd, GELU, casts/transposes of the weights,
+// global average pool, stem patchify, fused AdamW.  All move 16 bytes per lane and reduce with wave64 shuffles.
+//
+// Reference call sites these replace (third-party modules the reference instantiates):
+//   torchvision LayerNorm2d / nn.LayerNorm inside ConvNeXt  (mmgclip/networks/encoder.py:53 `features`)
+//   HF BertSelfOutput/BertOutput/BertEmbeddings LayerNorm   (mmgclip/networks/encoder.py:156)
+//   nn.LayerNorm of MLPProjectionHead                        (mmgclip/networks/projection.py:92,100)
+//   AdaptiveAvgPool2d                                        (mmgclip/networks/encoder.py:54)
+//   input scaling x*65535, (x-32767.5)/32767.5               (mmgclip/networks/image_features.py:95-99)
+//   torch.optim.AdamW                                        (mmgclip/experiments/ClassifierExperiment.py:74,118)
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim C of a bf16 [M,C] matrix.  A row is owned by a group of G lanes
+// (G = power of two >= C/8, <= 64), 64/G rows per wave, CH 16-byte chunks per lane.
+// `patch` != 0 : the normalised row m = (n,h,w) is written to (read from, in the backward) the 2x2-patchified
+// position  row (n, h/2, w/2), columns ((h&1)*2 + (w&1))*C ..  of a [M/4, 4C] matrix, so that the following
+// 2x2 stride-2 convolution is a plain GEMM (ConvNeXt downsample layers).
+// ---------------------------------------------------------------------------------------------
+struct LNArgs {
+    const bf16_t* x; int ldx;
+    const float* gamma; const float* beta; float eps;
+    bf16_t* y; int ldy;
+    float* mean; float* rstd;
+    int M, C;
+    int patch, H, W;     // patchified output (H, W = spatial dims of the INPUT rows)
+    // backward
+    const bf16_t* dy; int lddy;
+    bf16_t* dx; int lddx;
+    float* dgamma; float* dbeta;
+};
+
+__device__ __forceinline__ size_t ln_out_offset(const LNArgs& a, int m, int ld) {
+    if (!a.patch) return (size_t)m * ld;
+    const int w = m % a.W, h = (m / a.W) % a.H, n = m / (a.W * a.H);
+    const size_t prow = ((size_t)n * (a.H / 2) + (h >> 1)) * (a.W / 2) + (w >> 1);
+    return prow * ld + ((h & 1) * 2 + (w & 1)) * a.C;
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
+    f[0] = bf2f_lo(v.x); f[1] = bf2f_hi(v.x); f[2] = bf2f_lo(v.y); f[3] = bf2f_hi(v.y);
+    f[4] = bf2f_lo(v.z); f[5] = bf2f_hi(v.z); f[6] = bf2f_lo(v.w); f[7] = bf2f_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 o;
+    o.x = pack2bf(f[0], f[1]); o.y = pack2bf(f[2], f[3]); o.z = pack2bf(f[4], f[5]); o.w = pack2bf(f[6], f[7]);
+    return o;
+}
+
+template <int G, int CH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const LNArgs a) {
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gr = lane / G;
+    const int nchunks = a.C / 8;
+    const int rows_per_block = 4 * RPW;
+    for (int m = blockIdx.x * rows_per_block + wave * RPW + gr; m < a.M; m += gridDim.x * rows_per_block) {
+        float v[CH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = gl + k * G;
+            if (c < nchunks) {
+                unpack8(*reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx + c * 8), v[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[k][e];
+            }
+        }
+        s = group_sum<G>(s);
+        const float mu = s / a.C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = gl + k * G;
+            if (c < nchunks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mu; q += d * d; }
+            }
+        }
+        q = group_sum<G>(q);
+        const float rs = rsqrtf(q / a.C + a.eps);
+        const size_t obase = ln_out_offset(a, m, a.ldy);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = gl + k * G;
+            if (c < nchunks) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mu) * rs * a.gamma[c * 8 + e] + a.beta[c * 8 + e];
+                *reinterpret_cast<uint4*>(a.y + obase + c * 8) = pack8(o);
+            }
+        }
+        if (gl == 0) {
+            if (a.mean) a.mean[m] = mu;
+            if (a.rstd) a.rstd[m] = rs;
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma ; dgamma += sum dy*xhat ; dbeta += sum dy
+template <int G, int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LNArgs a) {
+    constexpr int RPW = 64 / G;
+    extern __shared__ float red[];    // [2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gr = lane / G;
+    const int nchunks = a.C / 8;
+    const int rows_per_block = 4 * RPW;
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float dg[CH][8], db[CH][8];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[k][e] = 0.f; db[k][e] = 0.f; }
+
+    for (int m = blockIdx.x * rows_per_block + wave * RPW + gr; m < a.M; m += gridDim.x * rows_per_block) {
+        const float mu = a.mean[m], rs = a.rstd[m];
+        const size_t gbase = ln_out_offset(a, m, a.lddy);
+        float xh[CH][8], g[CH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = gl + k * G;
+            if (c < nchunks) {
+                float xv[8], dyv[8];
+                unpack8(*reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx + c * 8), xv);
+                unpack8(*reinterpret_cast<const uint4*>(a.dy + gbase + c * 8), dyv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[k][e] = (xv[e] - mu) * rs;
+                    g[k][e] = dyv[e] * a.gamma[c * 8 + e];
+                    s1 += g[k][e];
+                    s2 += g[k][e] * xh[k][e];
+                    dg[k][e] += dyv[e] * xh[k][e];
+                    db[k][e] += dyv[e];
+                }
+            }
+        }
+        s1 = group_sum<G>(s1) / a.C;
+        s2 = group_sum<G>(s2) / a.C;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = gl + k * G;
+            if (c < nchunks) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (g[k][e] - s1 - xh[k][e] * s2);
+                *reinterpret_cast<uint4*>(a.dx + (size_t)m * a.lddx + c * 8) = pack8(o);
+            }
+        }
+    }
+    if (a.dgamma) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = gl + k * G;
+            if (c < nchunks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    atomicAdd(&red[c * 8 + e], dg[k][e]);
+                    atomicAdd(&red[a.C + c * 8 + e], db[k][e]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.C; i += 256) {
+            atomicAdd(a.dgamma + i, red[i]);
+            atomicAdd(a.dbeta + i, red[a.C + i]);
+        }
+    }
+}
+
+template <bool BWD>
+static int launch_ln(const LNArgs& a, hipStream_t stream) {
+    const int nch = a.C / 8;
+    int G = 8;
+    while (G < nch && G < 64) G <<= 1;
+    const int ch = cdiv(nch, G);
+    const int rows_per_block = 4 * (64 / G);
+    int blocks = cdiv(a.M, rows_per_block);
+    const int cap = BWD ? 1024 : 4096;
+    if (blocks > cap) blocks = cap;
+    const size_t shm = BWD ? 2 * a.C * sizeof(float) : 0;
+#define LN_LAUNCH(GG, CC)                                                                                       \
+    do {                                                                                                        \
+        if (BWD) hipLaunchKernelGGL((layernorm_bwd_kernel<GG, CC>), dim3(blocks), dim3(256), shm, stream, a);  \
+        else hipLaunchKernelGGL((layernorm_fwd_kernel<GG, CC>), dim3(blocks), dim3(256), 0, stream, a);        \
+    } while (0)
+    if (G == 8) LN_LAUNCH(8, 1);
+    else if (G == 16) LN_LAUNCH(16, 1);
+    else if (G == 32) LN_LAUNCH(32, 1);
+    else if (ch <= 1) LN_LAUNCH(64, 1);
+    else if (ch <= 2) LN_LAUNCH(64, 2);
+    else if (ch <= 4) LN_LAUNCH(64, 4);
+    else if (ch <= 8) LN_LAUNCH(64, 8);
+    else { mmg_set_error("layernorm: C=%d too wide (max 4096)", a.C); return 1; }
+#undef LN_LAUNCH
+    return 0;
+}
+
+static int ln_check(const char* who, int M, int C, int patch, int H, int W) {
+    MMG_CHECK_ARG(M > 0 && C >= 8 && C % 8 == 0 && C <= 4096, "%s: M=%d C=%d (C must be a multiple of 8, <= 4096)", who, M, C);
+    MMG_CHECK_ARG(!patch || (H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && M % (H * W) == 0),
+                  "%s: patchified layout needs even H=%d W=%d dividing M=%d", who, H, W, M);
+    return 0;
+}
+
+MMG_API int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
+                              float* mean, float* rstd, int M, int C, int patch, int H, int W, hipStream_t stream) {
+    if (ln_check("mmg_layernorm_fwd", M, C, patch, H, W)) return 1;
+    MMG_CHECK_ARG(x && gamma && beta && y && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= (patch ? 4 * C : C),
+                  "mmg_layernorm_fwd: bad pointer or leading dimension");
+    LNArgs a = {};
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps; a.y = (bf16_t*)y; a.ldy = ldy;
+    a.mean = mean; a.rstd = rstd; a.M = M; a.C = C; a.patch = patch; a.H = H; a.W = W;
+    if (launch_ln<false>(a, stream)) return 1;
+    MMG_LAUNCH_CHECK("mmg_layernorm_fwd");
+    return 0;
+}
+
+MMG_API int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                              const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta, int M, int C,
+                              int patch, int H, int W, hipStream_t stream) {
+    if (ln_check("mmg_layernorm_bwd", M, C, patch, H, W)) return 1;
+    MMG_CHECK_ARG(dy && x && mean && rstd && gamma && dx && ((dgamma == nullptr) == (dbeta == nullptr)) &&
+                      ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldx >= C && lddx >= C,
+                  "mmg_layernorm_bwd: bad pointer or leading dimension");
+    LNArgs a = {};
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
+    a.M = M; a.C = C; a.patch = patch; a.H = H; a.W = W;
+    a.dy = (const bf16_t*)dy; a.lddy = lddy; a.dx = (bf16_t*)dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta;
+    if (launch_ln<true>(a, stream)) return 1;
+    MMG_LAUNCH_CHECK("mmg_layernorm_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise
+// ---------------------------------------------------------------------------------------------
+// y = gelu(x) (bf16 -> bf16), n % 8 == 0; used to rebuild the FFN activation in the backward pass
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, size_t nvec) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        float f[8];
+        unpack8(reinterpret_cast<const uint4*>(x)[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = gelu_f(f[e]);
+        reinterpret_cast<uint4*>(y)[i] = pack8(f);
+    }
+}
+
+MMG_API int mmg_gelu_fwd_bf16(const void* x, void* y, long long n, hipStream_t stream) {
+    MMG_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "mmg_gelu_fwd_bf16: n=%lld must be a positive multiple of 8", n);
+    const size_t nvec = (size_t)n / 8;
+    int blocks = (int)((nvec + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, nvec);
+    MMG_LAUNCH_CHECK("mmg_gelu_fwd_bf16");
+    return 0;
+}
+
+// fp32 -> bf16 (any n)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = f2bf(x[i]);
+}
+MMG_API int mmg_cast_f32_bf16(const float* x, void* y, long long n, hipStream_t stream) {
+    MMG_CHECK_ARG(x && y && n > 0, "mmg_cast_f32_bf16: bad argument");
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, stream, x, (bf16_t*)y, (size_t)n);
+    MMG_LAUNCH_CHECK("mmg_cast_f32_bf16");
+    return 0;
+}
+// bf16 -> fp32
+__global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = bf2f(x[i]);
+}
+MMG_API int mmg_cast_bf16_f32(const void* x, float* y, long long n, hipStream_t stream) {
+    MMG_CHECK_ARG(x && y && n > 0, "mmg_cast_bf16_f32: bad argument");
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_f32_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, y, (size_t)n);
+    MMG_LAUNCH_CHECK("mmg_cast_bf16_f32");
+    return 0;
+}
+
+// dst[c, r] (bf16, ld = ldd) = rowscale[r] * src[r, c]  (fp32 [R,C]) : transposed bf16 copy of a weight for the
+// data-gradient GEMM; rowscale (nullable) folds ConvNeXt's layer scale into it.
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, int R, int C,
+                                                             const float* __restrict__ rowscale,
+                                                             bf16_t* __restrict__ dst, int ldd) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < C) ? src[(size_t)r * C + c] * (rowscale ? rowscale[r] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < C && r < R) dst[(size_t)c * ldd + r] = f2bf(tile[tx][j]);
+    }
+}
+MMG_API int mmg_transpose_cast_bf16(const float* src, int R, int C, const float* rowscale, void* dst, int ldd,
+                                    hipStream_t stream) {
+    MMG_CHECK_ARG(src && dst && R > 0 && C > 0 && ldd >= R, "mmg_transpose_cast_bf16: bad argument");
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, stream, src, R, C, rowscale,
+                       (bf16_t*)dst, ldd);
+    MMG_LAUNCH_CHECK("mmg_transpose_cast_bf16");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// global average pool over the HW rows of each image: x bf16 [n, HW, C] -> y [n, C] (fp32) ; backward broadcast
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int HW, int C) {
+    extern __shared__ float sums[];   // [C]
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < C; i += 256) sums[i] = 0.f;
+    __syncthreads();
+    const int ng = C / 8;
+    const int cg = threadIdx.x % ng, rl = threadIdx.x / ng, lanes_r = 256 / ng;
+    if (rl < lanes_r) {
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = rl + blockIdx.y * lanes_r; p < HW; p += lanes_r * gridDim.y) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + p) * C + cg * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&sums[cg * 8 + e], s[e]);
+    }
+    __syncthreads();
+    const float inv = 1.0f / HW;
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(y + (size_t)n * C + i, sums[i] * inv);
+}
+MMG_API int mmg_avgpool_fwd(const void* x, float* y, int n, int HW, int C, hipStream_t stream) {
+    MMG_CHECK_ARG(x && y && n > 0 && HW > 0 && C % 8 == 0 && C >= 8 && C <= 2048, "mmg_avgpool_fwd: bad argument");
+    if (hipMemsetAsync(y, 0, (size_t)n * C * sizeof(float), stream) != hipSuccess) { mmg_set_error("mmg_avgpool_fwd: memset failed"); return 2; }
+    int split = cdiv(HW, 256);
+    if (split > 16) split = 16;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(n, split), dim3(256), C * sizeof(float), stream, (const bf16_t*)x, y, HW, C);
+    MMG_LAUNCH_CHECK("mmg_avgpool_fwd");
+    return 0;
+}
+// dx[n, p, c] = dy[n, c] / HW  (bf16 out)
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, bf16_t* __restrict__ dx, int HW, int C,
+                                                          size_t nvec) {
+    const int ng = C / 8;
+    const float inv = 1.0f / HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % ng);
+        const size_t row = i / ng;
+        const size_t n = row / HW;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = dy[n * C + cg * 8 + e] * inv;
+        reinterpret_cast<uint4*>(dx)[i] = pack8(f);
+    }
+}
+MMG_API int mmg_avgpool_bwd(const float* dy, void* dx, int n, int HW, int C, hipStream_t stream) {
+    MMG_CHECK_ARG(dy && dx && n > 0 && HW > 0 && C % 8 == 0, "mmg_avgpool_bwd: bad argument");
+    const size_t nvec = (size_t)n * HW * C / 8;
+    int blocks = (int)((nvec + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, (bf16_t*)dx, HW, C, nvec);
+    MMG_LAUNCH_CHECK("mmg_avgpool_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem patchify: pixels [n, Cin, H, W] fp32 in [0,1] -> rows (n, h/P, w/P) x (kh, kw, cin) bf16, K padded to Kp.
+// `scale16` applies the reference's 16-bit scaling ((65535 x) - 32767.5) / 32767.5 (image_features.py:95-99).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int Cin,
+                                                       int H, int W, int P, int Kp, int scale16, size_t rows) {
+    const int Ho = H / P, Wo = W / P;
+    const int K = P * P * Cin;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < rows * Kp; idx += (size_t)gridDim.x * 256) {
+        const int k = (int)(idx % Kp);
+        const size_t row = idx / Kp;
+        float v = 0.f;
+        if (k < K) {
+            const int ci = k % Cin, kw = (k / Cin) % P, kh = k / (Cin * P);
+            const int wo = (int)(row % Wo), ho = (int)((row / Wo) % Ho);
+            const size_t n = row / ((size_t)Wo * Ho);
+            v = img[((n * Cin + ci) * H + (ho * P + kh)) * W + wo * P + kw];
+            if (scale16) v = (v * 65535.0f - 32767.5f) / 32767.5f;
+        }
+        out[idx] = f2bf(v);
+    }
+}
+MMG_API int mmg_patchify(const float* img, void* out, int n, int Cin, int H, int W, int P, int Kp, int scale16,
+                         hipStream_t stream) {
+    MMG_CHECK_ARG(img && out && n > 0 && Cin > 0 && P > 0 && H % P == 0 && W % P == 0 && Kp >= P * P * Cin && Kp % 8 == 0,
+                  "mmg_patchify: bad argument (H=%d W=%d P=%d Cin=%d Kp=%d)", H, W, P, Cin, Kp);
+    const size_t rows = (size_t)n * (H / P) * (W / P);
+    size_t total = rows * Kp;
+    int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, stream, img, (bf16_t*)out, Cin, H, W, P, Kp, scale16, rows);
+    MMG_LAUNCH_CHECK("mmg_patchify");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused AdamW over a flat fp32 parameter buffer (torch.optim.AdamW semantics, decoupled weight decay);
+// optionally refreshes the bf16 working copy in the same pass.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ p16, size_t n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                                                    float gscale) {
+    const float step = lr / bc1;
+    const float isbc2 = rsqrtf(bc2);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        pi -= step * mi / (sqrtf(vi) * isbc2 + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (p16) p16[i] = f2bf(pi);
+    }
+}
+MMG_API int mmg_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, float grad_scale, hipStream_t stream) {
+    MMG_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "mmg_adamw_step: bad argument");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, (size_t)n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    MMG_LAUNCH_CHECK("mmg_adamw_step");
+    return 0;
+}

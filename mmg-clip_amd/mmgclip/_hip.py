@@ -70,6 +70,9 @@ def load():
             raise HipLibraryError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+        # PyTorch bundles its own libamdhip64.so.7; it must be the ONE HIP runtime of the process (streams and
+        # device pointers are shared with it), so make sure it is loaded before our library resolves that SONAME.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes, _) in parse_header().items():
             try:
