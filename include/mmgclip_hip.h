@@ -103,6 +103,81 @@ int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, i
 /* Bias gradient: out[n] += sum_m A[m,n]  (A bf16 [M,N]). */
 int mmg_colsum_bf16(const void* A, int lda, int M, int N, float* out, mmg_stream_t stream);
 
+/* ---- LayerNorm / elementwise / pooling / optimiser (HBM-bound) --------------------------------------------- */
+
+/* y = (x - mean) * rstd * gamma + beta over the last dim C of bf16 x[M,C]; mean/rstd (fp32 [M], nullable) are saved
+ * for the backward.  patch != 0: row m = (n,h,w) of an [n,H,W] grid is written to the 2x2-patchified position
+ * row (n,h/2,w/2), columns ((h&1)*2+(w&1))*C of a [M/4, 4C] matrix (ConvNeXt downsample: the following 2x2/s2
+ * convolution becomes a GEMM).  Replaces nn.LayerNorm / LayerNorm2d of torchvision ConvNeXt and HF BERT
+ * (mmgclip/networks/encoder.py:53,156) and of MLPProjectionHead (mmgclip/networks/projection.py:100). */
+int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
+                      float* mean, float* rstd, int M, int C, int patch, int H, int W, mmg_stream_t stream);
+/* dx (bf16) and dgamma/dbeta (fp32, ACCUMULATED; both NULL to skip) given dy in the layout the forward wrote. */
+int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                      const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta, int M, int C, int patch,
+                      int H, int W, mmg_stream_t stream);
+
+/* y = GELU(x) elementwise, bf16, n % 8 == 0 (rebuilds the FFN activation in the backward pass). */
+int mmg_gelu_fwd_bf16(const void* x, void* y, long long n, mmg_stream_t stream);
+/* dtype conversions of flat buffers */
+int mmg_cast_f32_bf16(const float* x, void* y, long long n, mmg_stream_t stream);
+int mmg_cast_bf16_f32(const void* x, float* y, long long n, mmg_stream_t stream);
+/* dst[c,r] (bf16, ld ldd) = rowscale[r] * src[r,c] (fp32 [R,C]); rowscale nullable.  Transposed working copy of a
+ * weight for the data-gradient GEMM (layer scale folded in for ConvNeXt's second linear). */
+int mmg_transpose_cast_bf16(const float* src, int R, int C, const float* rowscale, void* dst, int ldd,
+                            mmg_stream_t stream);
+
+/* y[n,:] = mean over HW rows of bf16 x[n,HW,C] (fp32 out).  AdaptiveAvgPool2d(1), mmgclip/networks/encoder.py:54. */
+int mmg_avgpool_fwd(const void* x, float* y, int n, int HW, int C, mmg_stream_t stream);
+int mmg_avgpool_bwd(const float* dy, void* dx, int n, int HW, int C, mmg_stream_t stream);
+
+/* Stem im2col: fp32 pixels [n,Cin,H,W] -> bf16 rows (n,h/P,w/P) x (kh,kw,cin), zero-padded to Kp columns;
+ * scale16 != 0 applies ((65535 x) - 32767.5)/32767.5 (mmgclip/networks/image_features.py:95-99). */
+int mmg_patchify(const float* img, void* out, int n, int Cin, int H, int W, int P, int Kp, int scale16,
+                 mmg_stream_t stream);
+
+/* torch.optim.AdamW step over a flat fp32 buffer (mmgclip/experiments/ClassifierExperiment.py:74,118);
+ * p_bf16 (nullable) receives the refreshed bf16 working copy.  step counts from 1. */
+int mmg_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, mmg_stream_t stream);
+
+/* ---- depthwise 7x7 convolution, NHWC bf16 (ConvNeXt CNBlock) ------------------------------------------------ */
+
+/* y = dwconv7x7(x; w, bias) (+ add), padding 3; x,y,add bf16 [n,H,W,C]; w fp32 tap-major [49][C]
+ * (w[kh*7+kw][c] = weight[c,0,kh,kw]); flip != 0 reverses the taps (data gradient when x := dy).
+ * C % 32 == 0.  Replaces CNBlock.block[0] of torchvision ConvNeXt (mmgclip/networks/encoder.py:53). */
+int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, const void* add, void* y, int n, int H, int W,
+                     int C, int flip, mmg_stream_t stream);
+/* dw[49][C] += sum x(shifted) * dy ; dbias[C] += sum dy  (fp32, accumulated; dbias nullable) */
+int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int H, int W, int C,
+                      mmg_stream_t stream);
+
+/* ---- BERT attention / embeddings / pooling -------------------------------------------------------------------- */
+
+/* ctx[B*S,Hd] = per-head softmax(Q K^T * scale + key mask) V with qkv = [B*S, q|k|v] bf16 (head h at columns h*64
+ * of each third); mask int64 [B,S] (1 attend / 0 pad, nullable); lse fp32 [B,heads,S] (nullable) for the backward.
+ * head_dim 64, S <= 512.  Replaces HF BertSelfAttention (mmgclip/networks/encoder.py:156). */
+int mmg_attention_fwd(const void* qkv, int ld, const long long* mask, void* ctx, int ldc, float* lse, int B, int S,
+                      int heads, int Hd, float scale, mmg_stream_t stream);
+/* dqkv (same layout as qkv) from dctx; recomputes probabilities from lse.  S <= 256. */
+int mmg_attention_bwd(const void* qkv, int ld, const long long* mask, const void* ctx, int ldc, const float* lse,
+                      const void* dctx, int lddc, void* dqkv, int lddq, int B, int S, int heads, int Hd, float scale,
+                      mmg_stream_t stream);
+
+/* out[m,:] = word[ids[m]] + pos[m % S] + type[type_ids[m]] (bf16 tables [V|P|T, H]); HF BertEmbeddings before its
+ * LayerNorm (mmgclip/networks/encoder.py:156). */
+int mmg_bert_embed_fwd(const long long* ids, const long long* type_ids, const void* word, const void* pos,
+                       const void* type, void* out, int M, int S, int H, int V, int T, mmg_stream_t stream);
+/* table gradients (fp32, accumulated) from g = d out [B*S,H] bf16 */
+int mmg_bert_embed_bwd(const void* g, const long long* ids, const long long* type_ids, float* dword, float* dpos,
+                       float* dtype, int B, int S, int H, int V, int T, mmg_stream_t stream);
+
+/* EOS pooling: out[b,:] (fp32) = hidden[b, sum(mask[b])-1, :]; idx_out (int32 [B], nullable) keeps the index.
+ * Replaces mmgclip/networks/mmgclip_model.py:110-111. */
+int mmg_eos_pool_fwd(const void* hidden, const long long* mask, float* out, int* idx_out, int B, int S, int H,
+                     mmg_stream_t stream);
+int mmg_eos_pool_bwd(const float* dout, const int* idx, void* dhidden, int B, int S, int H, mmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

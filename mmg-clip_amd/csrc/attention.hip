@@ -1,0 +1,349 @@
+// Multi-head self-attention for the BERT text tower (gfx950): head_dim 64, key-padding mask, S <= 512 (forward)
+// and S <= 256 (backward).  Replaces HF BertSelfAttention (scores = QK^T/8 + mask, softmax, PV) reached from
+// mmgclip/networks/encoder.py:156 (`self.model(**x)`), config in notebooks/bert_experimental.ipynb:609-624.
+//
+// One workgroup per (sequence, head).  K, V (and Q, dO in the backward) live in LDS as ONE swizzled image each that
+// serves both row reads (ds_read_b128: the token is the MFMA row, head_dim is reduced) and transposed reads
+// (ds_read_b64_tr_b16: the token is reduced).  Scores are computed "swapped" (A = K tile, B = Q tile) so a lane owns
+// one query row: softmax statistics are register-local plus two shuffles, and the probability registers are fed
+// straight back as the B operand of P.V with the key order the transposed V read delivers (no LDS round trip for P).
+// The backward recomputes P from the saved log-sum-exp (no S x S tensor in HBM), pass 1 with a query row per lane
+// (dQ), pass 2 with a key per lane (dK, dV); every output row has exactly one writer, so there are no atomics.
+#include "common.h"
+
+#define ATT_D 64
+#define ATT_NEG (-1.0e30f)
+
+// byte offset of 16-byte chunk c (0..7) of token row r in a swizzled [rows][64] bf16 image (128-byte rows)
+__device__ __forceinline__ int att_off(int r, int c) { return r * 128 + (((((c >> 1) ^ (r >> 1)) & 3) << 1) | (c & 1)) * 16; }
+
+// stage rows [0,S) of a [.,64]-wide head slice (global row stride ld elements) into the image; rows >= S are zero
+__device__ __forceinline__ void att_stage(const bf16_t* __restrict__ src, int ld, char* img, int S, int S_pad) {
+    for (int idx = threadIdx.x; idx < S_pad * 8; idx += 256) {
+        const int r = idx >> 3, c = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < S) v = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + c * 8);
+        *reinterpret_cast<uint4*>(img + att_off(r, c)) = v;
+    }
+}
+
+// row fragment: lane (li, g) gets img[r0 + li][32*ks + 8*g .. +7]
+__device__ __forceinline__ bf16x8 att_row_frag(const char* img, int r0, int ks, int lane) {
+    const int r = r0 + (lane & 15), c = 4 * ks + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(img + att_off(r, c));
+}
+
+// transposed fragment over 32 tokens starting at t0 for the 16 columns dt*16..: lane (i, g) gets
+//   element j<4 : img[t0 + 4g + j][dt*16 + i],   element j>=4 : img[t0 + 16 + 4g + (j-4)][dt*16 + i]
+__device__ __forceinline__ bf16x8 att_tr_frag(const char* img, int t0, int dt, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
+    const int ra = t0 + 4 * g + q4, rb = ra + 16;
+    const int c = dt * 2 + (p >> 1);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(img + att_off(ra, c) + (p & 1) * 8));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(img + att_off(rb, c) + (p & 1) * 8));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4 a, const f32x4 b) {
+    bf16x8 r;
+    r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
+    r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
+    return r;
+}
+
+__device__ __forceinline__ float group4_max(float v) {   // across the 4 lane groups (lane>>4) of one column
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+struct AttArgs {
+    const bf16_t* qkv; int ld;          // [B*S, 3*Hd] : q | k | v, head h at columns h*64
+    const long long* mask;              // [B,S] 1 = attend, 0 = padding (nullable)
+    bf16_t* ctx; int ldc;               // [B*S, Hd]
+    float* lse;                         // [B, heads, S]
+    int S, S_pad, heads, Hd;
+    float scale;
+    // backward
+    const bf16_t* dctx; int lddc;       // [B*S, Hd]
+    bf16_t* dqkv; int lddq;             // [B*S, 3*Hd]
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int NT>   // NT >= S_pad / 16
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + a.S_pad * 128;
+    float* madd = reinterpret_cast<float*>(smem + 2 * a.S_pad * 128);
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
+    att_stage(base + a.Hd, a.ld, Ks, a.S, a.S_pad);
+    att_stage(base + 2 * a.Hd, a.ld, Vs, a.S, a.S_pad);
+    for (int k = threadIdx.x; k < a.S_pad; k += 256)
+        madd[k] = (k < a.S && (!a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
+    __syncthreads();
+
+    const int ntile = a.S_pad / 16;
+    for (int qt = wave; qt < ntile; qt += 4) {
+        const int q0 = qt * 16;
+        const int qrow = min(q0 + li, a.S - 1);
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * a.ld + ks * 32 + g * 8);
+        f32x4 sc[NT];
+        float m = ATT_NEG;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < ntile) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(madd + t * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[r] = acc[r] * a.scale + mk[r];
+                    m = fmaxf(m, acc[r]);
+                }
+                sc[t] = acc;
+            }
+        }
+        m = group4_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < ntile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[t][r] = __expf(sc[t][r] - m);
+                    l += sc[t][r];
+                }
+            }
+        }
+        l = group4_sum(l);
+        const float inv = 1.0f / l;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NT / 2; ++c) {
+            if (2 * c < ntile) {
+                const bf16x8 pf = pack_frag(sc[2 * c] * inv, sc[2 * c + 1] * inv);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Vs, c * 32, dt, lane), pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q0 + li < a.S) {
+            bf16_t* dst = a.ctx + ((size_t)b * a.S + q0 + li) * a.ldc + h * ATT_D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 v;
+                v.x = pack2bf(o[dt][0], o[dt][1]);
+                v.y = pack2bf(o[dt][2], o[dt][3]);
+                *reinterpret_cast<uint2*>(dst + dt * 16) = v;
+            }
+            if (g == 0 && a.lse) a.lse[((size_t)b * a.heads + h) * a.S + q0 + li] = m + __logf(l);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: dqkv <- (dQ | dK | dV) of this head.  S_pad <= 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int img = a.S_pad * 128;
+    char* Qs = smem;
+    char* Ks = smem + img;
+    char* Vs = smem + 2 * img;
+    char* Gs = smem + 3 * img;                                       // dO (gradient of the context)
+    float* madd = reinterpret_cast<float*>(smem + 4 * img);          // [S_pad]
+    float* lses = madd + a.S_pad;                                    // [S_pad]
+    float* delta = lses + a.S_pad;                                   // [S_pad] rowsum(dO * O)
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
+    const bf16_t* gbase = a.dctx + (size_t)b * a.S * a.lddc + h * ATT_D;
+    const bf16_t* obase = a.ctx + (size_t)b * a.S * a.ldc + h * ATT_D;
+    att_stage(base, a.ld, Qs, a.S, a.S_pad);
+    att_stage(base + a.Hd, a.ld, Ks, a.S, a.S_pad);
+    att_stage(base + 2 * a.Hd, a.ld, Vs, a.S, a.S_pad);
+    att_stage(gbase, a.lddc, Gs, a.S, a.S_pad);
+    for (int k = threadIdx.x; k < a.S_pad; k += 256) {
+        madd[k] = (k < a.S && (!a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
+        lses[k] = k < a.S ? a.lse[((size_t)b * a.heads + h) * a.S + k] : 1.0e30f;
+    }
+    // delta[q] = sum_d dO[q,d] * O[q,d] : 4 lanes per row, 16 columns each
+    for (int idx = threadIdx.x; idx < a.S_pad * 4; idx += 256) {
+        const int r = idx >> 2, part = idx & 3;
+        float s = 0.f;
+        if (r < a.S) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint4 gv = *reinterpret_cast<const uint4*>(gbase + (size_t)r * a.lddc + part * 16 + c * 8);
+                const uint4 ov = *reinterpret_cast<const uint4*>(obase + (size_t)r * a.ldc + part * 16 + c * 8);
+                const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += bf2f_lo(gw[e]) * bf2f_lo(ow[e]) + bf2f_hi(gw[e]) * bf2f_hi(ow[e]);
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (part == 0) delta[r] = s;
+    }
+    __syncthreads();
+
+    const int ntile = a.S_pad / 16, nchunk = a.S_pad / 32;
+    // ---- pass 1: a query row per lane -> dQ -------------------------------------------------
+    for (int qt = wave; qt < ntile; qt += 4) {
+        const int q0 = qt * 16;
+        const bf16x8 qf0 = att_row_frag(Qs, q0, 0, lane), qf1 = att_row_frag(Qs, q0, 1, lane);
+        const bf16x8 gf0 = att_row_frag(Gs, q0, 0, lane), gf1 = att_row_frag(Gs, q0, 1, lane);
+        const float lq = lses[q0 + li], dq_ = delta[q0 + li];
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunk; ++c) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k0 = c * 32 + t * 16;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, k0, 0, lane), qf0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, k0, 1, lane), qf1, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Vs, k0, 0, lane), gf0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Vs, k0, 1, lane), gf1, dp, 0, 0, 0);
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(madd + k0 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(s[r] * a.scale + mk[r] - lq);
+                    ds[t][r] = p * (dp[r] - dq_) * a.scale;
+                }
+            }
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Ks, c * 32, dt, lane), dsf, dq[dt], 0, 0, 0);
+        }
+        if (q0 + li < a.S) {
+            bf16_t* dst = a.dqkv + ((size_t)b * a.S + q0 + li) * a.lddq + h * ATT_D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 v;
+                v.x = pack2bf(dq[dt][0], dq[dt][1]);
+                v.y = pack2bf(dq[dt][2], dq[dt][3]);
+                *reinterpret_cast<uint2*>(dst + dt * 16) = v;
+            }
+        }
+    }
+    // ---- pass 2: a key per lane -> dK, dV ---------------------------------------------------
+    for (int kt = wave; kt < ntile; kt += 4) {
+        const int k0 = kt * 16;
+        const bf16x8 kf0 = att_row_frag(Ks, k0, 0, lane), kf1 = att_row_frag(Ks, k0, 1, lane);
+        const bf16x8 vf0 = att_row_frag(Vs, k0, 0, lane), vf1 = att_row_frag(Vs, k0, 1, lane);
+        const float mk = madd[k0 + li];
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int c = 0; c < nchunk; ++c) {
+            f32x4 pp[2], ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q0 = c * 32 + t * 16;
+                // D[row = q (4g + r)][col = key li]
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Qs, q0, 0, lane), kf0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Qs, q0, 1, lane), kf1, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Gs, q0, 0, lane), vf0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Gs, q0, 1, lane), vf1, dp, 0, 0, 0);
+                const f32x4 lq = *reinterpret_cast<const f32x4*>(lses + q0 + 4 * g);
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(delta + q0 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(s[r] * a.scale + mk - lq[r]);
+                    pp[t][r] = p;
+                    ds[t][r] = p * (dp[r] - dl[r]) * a.scale;
+                }
+            }
+            const bf16x8 pf = pack_frag(pp[0], pp[1]), dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Gs, c * 32, dt, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Qs, c * 32, dt, lane), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (k0 + li < a.S) {
+            bf16_t* dst = a.dqkv + ((size_t)b * a.S + k0 + li) * a.lddq + h * ATT_D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 v;
+                v.x = pack2bf(dk[dt][0], dk[dt][1]);
+                v.y = pack2bf(dk[dt][2], dk[dt][3]);
+                *reinterpret_cast<uint2*>(dst + a.Hd + dt * 16) = v;
+                v.x = pack2bf(dv[dt][0], dv[dt][1]);
+                v.y = pack2bf(dv[dt][2], dv[dt][3]);
+                *reinterpret_cast<uint2*>(dst + 2 * a.Hd + dt * 16) = v;
+            }
+        }
+    }
+}
+
+static int att_check(const char* who, int B, int S, int heads, int Hd, int ld, int smax) {
+    MMG_CHECK_ARG(B > 0 && S > 0 && S <= smax, "%s: S=%d must be in [1,%d]", who, S, smax);
+    MMG_CHECK_ARG(heads > 0 && Hd == heads * ATT_D, "%s: hidden=%d must equal heads=%d x 64", who, Hd, heads);
+    MMG_CHECK_ARG(ld >= 3 * Hd && ld % 8 == 0, "%s: qkv leading dimension %d", who, ld);
+    return 0;
+}
+
+// ctx = softmax(Q K^T * scale + key_mask) V per head; lse (nullable) receives the row log-sum-exp for the backward.
+MMG_API int mmg_attention_fwd(const void* qkv, int ld, const long long* mask, void* ctx, int ldc, float* lse, int B, int S,
+                              int heads, int Hd, float scale, hipStream_t stream) {
+    if (att_check("mmg_attention_fwd", B, S, heads, Hd, ld, 512)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && ldc >= Hd && ldc % 8 == 0, "mmg_attention_fwd: bad ctx");
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = lse;
+    a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    const size_t shm = (size_t)2 * a.S_pad * 128 + a.S_pad * 4;
+    const dim3 grid(B * heads);
+    const int nt = a.S_pad / 16;
+#define ATT_FWD(NT)                                                                                   \
+    do {                                                                                              \
+        mmg_allow_lds(attn_fwd_kernel<NT>, shm);                                                      \
+        hipLaunchKernelGGL(attn_fwd_kernel<NT>, grid, dim3(256), shm, stream, a);                     \
+    } while (0)
+    if (nt <= 6) ATT_FWD(6);
+    else if (nt <= 8) ATT_FWD(8);
+    else if (nt <= 16) ATT_FWD(16);
+    else ATT_FWD(32);
+#undef ATT_FWD
+    MMG_LAUNCH_CHECK("mmg_attention_fwd");
+    return 0;
+}
+
+// dqkv[:, q|k|v of every head] = gradients given dctx; needs the forward's ctx and lse.  S <= 256.
+MMG_API int mmg_attention_bwd(const void* qkv, int ld, const long long* mask, const void* ctx, int ldc, const float* lse,
+                              const void* dctx, int lddc, void* dqkv, int lddq, int B, int S, int heads, int Hd, float scale,
+                              hipStream_t stream) {
+    if (att_check("mmg_attention_bwd", B, S, heads, Hd, ld, 256)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && ldc >= Hd && lddc >= Hd && lddq >= 3 * Hd && ldc % 8 == 0 &&
+                      lddc % 8 == 0 && lddq % 8 == 0, "mmg_attention_bwd: bad pointer or leading dimension");
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = const_cast<float*>(lse);
+    a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    a.dctx = (const bf16_t*)dctx; a.lddc = lddc; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
+    const size_t shm = (size_t)4 * a.S_pad * 128 + 3 * a.S_pad * 4;
+    mmg_allow_lds(attn_bwd_kernel, shm);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), shm, stream, a);
+    MMG_LAUNCH_CHECK("mmg_attention_bwd");
+    return 0;
+}

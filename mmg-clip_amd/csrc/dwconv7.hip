@@ -1,0 +1,220 @@
+// Depthwise 7x7 convolution (padding 3, stride 1) in NHWC bf16 for the ConvNeXt blocks (gfx950).
+//
+// Replaces torchvision CNBlock's Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim, bias=True) inside the
+// `features` of the reference's ConvNeXt archive (mmgclip/networks/encoder.py:53,
+// mmgclip/networks/image_features.py:100; module tree in notebooks/clf_convnext_tiny_experimental.ipynb cell 3).
+//
+// Not a GEMM: 49 MAC per output and no channel reduction, so it runs on the fp32 VALU with the tile in LDS.
+// A workgroup owns a 16x32 pixel tile of a 32-channel slab: the (16+6)x(32+6) halo tile is staged once
+// (16-byte coalesced loads, zero padded), a lane owns a channel pair and a strip of 8 output pixels along W and
+// slides the 7-tap window over a row of 14 inputs held in registers (56 packed FMAs per 14 LDS reads).
+// The same kernel with the taps flipped is the data gradient; the weight gradient keeps the 49 taps of its channel
+// pair in registers across tiles and images and reduces through LDS into one atomic per tap per workgroup.
+#include "common.h"
+
+#define DW_TW 32
+#define DW_TH 16
+#define DW_CB 32
+#define DW_COLS (DW_TW + 6)
+#define DW_ROWS (DW_TH + 6)
+#define DW_ROWD (DW_COLS * (DW_CB / 2) + 16)   // dwords per LDS row; +16 keeps rows r, r+1 on disjoint bank halves
+
+// stage the halo tile of image n (tile origin h0,w0; channel slab c0) into LDS, zero outside the image
+__device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ x, unsigned* tile, int n, int H, int W, int C, int h0,
+                                         int w0, int c0) {
+    constexpr int CHUNKS = DW_ROWS * DW_COLS * (DW_CB / 8);
+    for (int idx = threadIdx.x; idx < CHUNKS; idx += 256) {
+        const int ch = idx & 3, pix = idx >> 2;
+        const int col = pix % DW_COLS, row = pix / DW_COLS;
+        const int gh = h0 - 3 + row, gw = w0 - 3 + col;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gh >= 0 && gh < H && gw >= 0 && gw < W)
+            v = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + gh) * W + gw) * C + c0 + ch * 8);
+        *reinterpret_cast<uint4*>(tile + row * DW_ROWD + col * (DW_CB / 2) + ch * 4) = v;
+    }
+}
+
+template <bool FLIP>
+__global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const bf16_t* __restrict__ add,
+                                                         bf16_t* __restrict__ y, int H, int W, int C, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+    unsigned* tile = smem_u;                                             // [DW_ROWS][DW_ROWD] dwords (bf16 pairs)
+    float* ws = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD);    // [49][32]
+    const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+    const int c0 = blockIdx.y * DW_CB, n = blockIdx.z;
+    const int h0 = th * DW_TH, w0 = tw * DW_TW;
+    const int cp = threadIdx.x & 15, r4 = (threadIdx.x >> 4) & 3, strip = threadIdx.x >> 6;
+
+    for (int i = threadIdx.x; i < 49 * DW_CB; i += 256) {
+        const int k = i / DW_CB, c = i % DW_CB;
+        ws[i] = w[(size_t)(FLIP ? 48 - k : k) * C + c0 + c];
+    }
+    dw_stage(x, tile, n, H, W, C, h0, w0, c0);
+    __syncthreads();
+
+    const float b0 = bias ? bias[c0 + 2 * cp] : 0.f, b1 = bias ? bias[c0 + 2 * cp + 1] : 0.f;
+#pragma unroll 1
+    for (int pass = 0; pass < DW_TH / 4; ++pass) {
+        const int oh = pass * 4 + r4;
+        float a0[8], a1[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { a0[p] = b0; a1[p] = b1; }
+#pragma unroll 1
+        for (int kh = 0; kh < 7; ++kh) {
+            const unsigned* rowp = tile + (oh + kh) * DW_ROWD + (strip * 8) * (DW_CB / 2) + cp;
+            float i0[14], i1[14];
+#pragma unroll
+            for (int q = 0; q < 14; ++q) {
+                const unsigned v = rowp[q * (DW_CB / 2)];
+                i0[q] = bf2f_lo(v);
+                i1[q] = bf2f_hi(v);
+            }
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float2 wv = *reinterpret_cast<const float2*>(ws + (kh * 7 + kw) * DW_CB + 2 * cp);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    a0[p] = fmaf(wv.x, i0[p + kw], a0[p]);
+                    a1[p] = fmaf(wv.y, i1[p + kw], a1[p]);
+                }
+            }
+        }
+        const int gh = h0 + oh;
+        if (gh < H) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int gw = w0 + strip * 8 + p;
+                if (gw < W) {
+                    const size_t off = (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp;
+                    float v0 = a0[p], v1 = a1[p];
+                    if (add) {
+                        const unsigned r = *reinterpret_cast<const unsigned*>(add + off);
+                        v0 += bf2f_lo(r);
+                        v1 += bf2f_hi(r);
+                    }
+                    *reinterpret_cast<unsigned*>(y + off) = pack2bf(v0, v1);
+                }
+            }
+        }
+    }
+}
+
+// dw[k][c] += sum_{n,h,w} x[n, h+kh-3, w+kw-3, c] * dy[n,h,w,c] ;  dbias[c] += sum dy
+__global__ __launch_bounds__(256, 1) void dwconv7_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                               float* __restrict__ dw, float* __restrict__ dbias, int N,
+                                                               int H, int W, int C, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+    unsigned* tile = smem_u;
+    float* red = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD);    // [50][32]
+    const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+    const int c0 = blockIdx.y * DW_CB;
+    const int h0 = th * DW_TH, w0 = tw * DW_TW;
+    const int cp = threadIdx.x & 15, r4 = (threadIdx.x >> 4) & 3, strip = threadIdx.x >> 6;
+
+    float d0[49], d1[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) { d0[k] = 0.f; d1[k] = 0.f; }
+    float sb0 = 0.f, sb1 = 0.f;
+
+    for (int n = blockIdx.z; n < N; n += gridDim.z) {
+        __syncthreads();
+        dw_stage(x, tile, n, H, W, C, h0, w0, c0);
+        __syncthreads();
+#pragma unroll 1
+        for (int pass = 0; pass < DW_TH / 4; ++pass) {
+            const int oh = pass * 4 + r4;
+            const int gh = h0 + oh;
+            float g0[8], g1[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int gw = w0 + strip * 8 + p;
+                unsigned v = 0;
+                if (gh < H && gw < W) v = *reinterpret_cast<const unsigned*>(dy + (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp);
+                g0[p] = bf2f_lo(v);
+                g1[p] = bf2f_hi(v);
+                sb0 += g0[p];
+                sb1 += g1[p];
+            }
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) {
+                const unsigned* rowp = tile + (oh + kh) * DW_ROWD + (strip * 8) * (DW_CB / 2) + cp;
+                float i0[14], i1[14];
+#pragma unroll
+                for (int q = 0; q < 14; ++q) {
+                    const unsigned v = rowp[q * (DW_CB / 2)];
+                    i0[q] = bf2f_lo(v);
+                    i1[q] = bf2f_hi(v);
+                }
+#pragma unroll
+                for (int kw = 0; kw < 7; ++kw) {
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        d0[kh * 7 + kw] = fmaf(i0[p + kw], g0[p], d0[kh * 7 + kw]);
+                        d1[kh * 7 + kw] = fmaf(i1[p + kw], g1[p], d1[kh * 7 + kw]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 50 * DW_CB; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 49; ++k) {
+        atomicAdd(&red[k * DW_CB + 2 * cp], d0[k]);
+        atomicAdd(&red[k * DW_CB + 2 * cp + 1], d1[k]);
+    }
+    atomicAdd(&red[49 * DW_CB + 2 * cp], sb0);
+    atomicAdd(&red[49 * DW_CB + 2 * cp + 1], sb1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 49 * DW_CB; i += 256) atomicAdd(dw + (size_t)(i / DW_CB) * C + c0 + (i % DW_CB), red[i]);
+    if (dbias && threadIdx.x < DW_CB) atomicAdd(dbias + c0 + threadIdx.x, red[49 * DW_CB + threadIdx.x]);
+}
+
+static int dw_check(const char* who, int n, int H, int W, int C) {
+    MMG_CHECK_ARG(n > 0 && H > 0 && W > 0 && C > 0 && C % DW_CB == 0 && n <= 65535 && C / DW_CB <= 65535,
+                  "%s: n=%d H=%d W=%d C=%d (C must be a multiple of 32)", who, n, H, W, C);
+    return 0;
+}
+
+// y = dwconv7(x; w, bias) (+ add).  w is tap-major fp32 [49][C] (w[kh*7+kw][c] = weight[c,0,kh,kw]).
+// flip != 0 uses the taps reversed: with x := dy this is the gradient w.r.t. the input.
+MMG_API int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, const void* add, void* y, int n, int H,
+                             int W, int C, int flip, hipStream_t stream) {
+    if (dw_check("mmg_dwconv7_nhwc", n, H, W, C)) return 1;
+    MMG_CHECK_ARG(x && w && y, "mmg_dwconv7_nhwc: null pointer");
+    const int tiles_w = cdiv(W, DW_TW), tiles_h = cdiv(H, DW_TH);
+    const size_t shm = (size_t)DW_ROWS * DW_ROWD * 4 + 49 * DW_CB * 4;
+    const dim3 grid(tiles_w * tiles_h, C / DW_CB, n);
+    if (flip) {
+        mmg_allow_lds(dwconv7_kernel<true>, shm);
+        hipLaunchKernelGGL(dwconv7_kernel<true>, grid, dim3(256), shm, stream, (const bf16_t*)x, w, bias, (const bf16_t*)add,
+                           (bf16_t*)y, H, W, C, tiles_w);
+    } else {
+        mmg_allow_lds(dwconv7_kernel<false>, shm);
+        hipLaunchKernelGGL(dwconv7_kernel<false>, grid, dim3(256), shm, stream, (const bf16_t*)x, w, bias, (const bf16_t*)add,
+                           (bf16_t*)y, H, W, C, tiles_w);
+    }
+    MMG_LAUNCH_CHECK("mmg_dwconv7_nhwc");
+    return 0;
+}
+
+// dw[49][C] += ..., dbias[C] += ...   (fp32, atomics; caller zeroes once per step)
+MMG_API int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int H, int W, int C,
+                              hipStream_t stream) {
+    if (dw_check("mmg_dwconv7_wgrad", n, H, W, C)) return 1;
+    MMG_CHECK_ARG(x && dy && dw, "mmg_dwconv7_wgrad: null pointer");
+    const int tiles_w = cdiv(W, DW_TW), tiles_h = cdiv(H, DW_TH);
+    const size_t shm = (size_t)DW_ROWS * DW_ROWD * 4 + 50 * DW_CB * 4;
+    // enough workgroups to fill the chip, but few enough image-slices that the tap registers amortise the atomics
+    int zs = 1;
+    const int per_img = tiles_w * tiles_h * (C / DW_CB);
+    while (zs < n && per_img * zs < 1024) zs <<= 1;
+    if (zs > n) zs = n;
+    mmg_allow_lds(dwconv7_wgrad_kernel, shm);
+    hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3(tiles_w * tiles_h, C / DW_CB, zs), dim3(256), shm, stream,
+                       (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w);
+    MMG_LAUNCH_CHECK("mmg_dwconv7_wgrad");
+    return 0;
+}

@@ -1,0 +1,141 @@
+"""Functional host wrappers (no autograd) over the HBM-bound / conv / attention entry points of the HIP library.
+
+Shapes follow the device layout: activations are bf16 row-major [rows, channels] (NHWC flattened for images).
+"""
+import torch
+
+from ._hip import call, ptr, stream
+
+BF16 = torch.bfloat16
+
+
+def layernorm_fwd(x, gamma, beta, eps, patch_hw=None, want_stats=True):
+    """x bf16 [M,C] -> y (bf16 [M,C] or the 2x2-patchified [M/4,4C] when patch_hw=(H,W)), mean, rstd."""
+    M, C = x.shape
+    if patch_hw is None:
+        y = torch.empty(M, C, device=x.device, dtype=BF16)
+        patch, H, W = 0, 0, 0
+    else:
+        H, W = patch_hw
+        y = torch.empty(M // 4, 4 * C, device=x.device, dtype=BF16)
+        patch = 1
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
+    call("mmg_layernorm_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), float(eps), ptr(y), y.stride(0), ptr(mean),
+         ptr(rstd), M, C, patch, H, W, stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, patch_hw=None, out=None):
+    M, C = x.shape
+    dx = out if out is not None else torch.empty(M, C, device=x.device, dtype=BF16)
+    patch, H, W = (0, 0, 0) if patch_hw is None else (1, patch_hw[0], patch_hw[1])
+    call("mmg_layernorm_bwd", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+         dx.stride(0), ptr(dgamma), ptr(dbeta), M, C, patch, H, W, stream())
+    return dx
+
+
+def gelu(x, out=None):
+    y = out if out is not None else torch.empty_like(x)
+    call("mmg_gelu_fwd_bf16", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def cast_bf16(x, out=None):
+    y = out if out is not None else torch.empty(x.shape, device=x.device, dtype=BF16)
+    call("mmg_cast_f32_bf16", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def cast_f32(x, out=None):
+    y = out if out is not None else torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    call("mmg_cast_bf16_f32", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def transpose_cast_bf16(w, rowscale=None, out=None):
+    """fp32 [R,C] -> bf16 [C,R] (optionally rows scaled first)."""
+    R, C = w.shape
+    y = out if out is not None else torch.empty(C, R, device=w.device, dtype=BF16)
+    call("mmg_transpose_cast_bf16", ptr(w), R, C, ptr(rowscale), ptr(y), y.stride(0), stream())
+    return y
+
+
+def avgpool_fwd(x, n, HW, C):
+    y = torch.empty(n, C, device=x.device, dtype=torch.float32)
+    call("mmg_avgpool_fwd", ptr(x), ptr(y), n, HW, C, stream())
+    return y
+
+
+def avgpool_bwd(dy, n, HW, C, out=None):
+    dx = out if out is not None else torch.empty(n * HW, C, device=dy.device, dtype=BF16)
+    call("mmg_avgpool_bwd", ptr(dy), ptr(dx), n, HW, C, stream())
+    return dx
+
+
+def patchify(img, P, Kp, scale16):
+    n, Cin, H, W = img.shape
+    out = torch.empty(n * (H // P) * (W // P), Kp, device=img.device, dtype=BF16)
+    call("mmg_patchify", ptr(img), ptr(out), n, Cin, H, W, P, Kp, 1 if scale16 else 0, stream())
+    return out
+
+
+def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    call("mmg_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), p.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), float(wd), int(step), float(grad_scale), stream())
+
+
+def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None):
+    y = out if out is not None else torch.empty(n * H * W, C, device=x.device, dtype=BF16)
+    call("mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream())
+    return y
+
+
+def dwconv7_wgrad(x, dy, dw49, dbias, n, H, W, C):
+    call("mmg_dwconv7_wgrad", ptr(x), ptr(dy), ptr(dw49), ptr(dbias), n, H, W, C, stream())
+
+
+def attention_fwd(qkv, mask, B, S, heads, want_lse=True):
+    Hd = heads * 64
+    ctx = torch.empty(B * S, Hd, device=qkv.device, dtype=BF16)
+    lse = torch.empty(B, heads, S, device=qkv.device, dtype=torch.float32) if want_lse else None
+    call("mmg_attention_fwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), Hd, ptr(lse), B, S, heads, Hd, 0.125, stream())
+    return ctx, lse
+
+
+def attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, out=None):
+    Hd = heads * 64
+    dqkv = out if out is not None else torch.empty(B * S, 3 * Hd, device=qkv.device, dtype=BF16)
+    call("mmg_attention_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),
+         dctx.stride(0), ptr(dqkv), dqkv.stride(0), B, S, heads, Hd, 0.125, stream())
+    return dqkv
+
+
+def bert_embed_fwd(ids, type_ids, word, pos, typ, S):
+    M = ids.numel()
+    H = word.shape[1]
+    out = torch.empty(M, H, device=word.device, dtype=BF16)
+    call("mmg_bert_embed_fwd", ptr(ids), ptr(type_ids), ptr(word), ptr(pos), ptr(typ), ptr(out), M, S, H, word.shape[0],
+         typ.shape[0], stream())
+    return out
+
+
+def bert_embed_bwd(g, ids, type_ids, dword, dpos, dtype, B, S):
+    H = g.shape[1]
+    call("mmg_bert_embed_bwd", ptr(g), ptr(ids), ptr(type_ids), ptr(dword), ptr(dpos), ptr(dtype), B, S, H,
+         dword.shape[0], dtype.shape[0], stream())
+
+
+def eos_pool_fwd(hidden, mask, B, S):
+    H = hidden.shape[1]
+    out = torch.empty(B, H, device=hidden.device, dtype=torch.float32)
+    idx = torch.empty(B, device=hidden.device, dtype=torch.int32)
+    call("mmg_eos_pool_fwd", ptr(hidden), ptr(mask), ptr(out), ptr(idx), B, S, H, stream())
+    return out, idx
+
+
+def eos_pool_bwd(dout, idx, B, S):
+    H = dout.shape[1]
+    dh = torch.empty(B * S, H, device=dout.device, dtype=BF16)
+    call("mmg_eos_pool_bwd", ptr(dout), ptr(idx), ptr(dh), B, S, H, stream())
+    return dh

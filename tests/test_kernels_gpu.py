@@ -1,0 +1,200 @@
+"""HBM-bound / conv / attention kernels vs plain PyTorch fp32 references of the same ops (bf16-rounded inputs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _r(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def _close(a, b, rtol, atol):
+    np.testing.assert_allclose(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("M,C", [(1024, 96), (777, 192), (512, 384), (300, 768), (64, 3072), (33, 64)])
+def test_layernorm_fwd_bwd(dev, M, C):
+    from mmgclip import kernels as K
+    x = _r((M, C), dev, 1, 2.0).to(BF)
+    gamma, beta = _r((C,), dev, 2).abs() + 0.5, _r((C,), dev, 3)
+    y, mean, rstd = K.layernorm_fwd(x, gamma, beta, 1e-6)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    _close(y, ref, 1e-2, 2e-2)
+    dy = _r((M, C), dev, 4).to(BF)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx = K.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db)
+    ref.backward(dy.float())
+    _close(dx, xr.grad, 2e-2, 2e-2)
+    _close(dg, gr.grad, 1e-3, 1e-2 * M ** 0.5 * 0.05 + 1e-3)
+    _close(db, br.grad, 1e-3, 1e-3 * M ** 0.5)
+
+
+def test_layernorm_patchified(dev):
+    """LN writing the 2x2-patchified layout == LN then unfold(2,2) in (kh,kw,c) order."""
+    from mmgclip import kernels as K
+    n, H, W, C = 2, 8, 12, 96
+    x = _r((n * H * W, C), dev, 5).to(BF)
+    gamma, beta = _r((C,), dev, 6).abs() + 0.5, _r((C,), dev, 7)
+    y, mean, rstd = K.layernorm_fwd(x, gamma, beta, 1e-6, patch_hw=(H, W))
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-6).reshape(n, H // 2, 2, W // 2, 2, C)
+    ref = ref.permute(0, 1, 3, 2, 4, 5).reshape(n * (H // 2) * (W // 2), 4 * C)
+    _close(y, ref, 1e-2, 2e-2)
+    dyp = _r((n * (H // 2) * (W // 2), 4 * C), dev, 8).to(BF)
+    dx = K.layernorm_bwd(dyp, x, mean, rstd, gamma, None, None, patch_hw=(H, W))
+    xr = x.float().requires_grad_(True)
+    r2 = F.layer_norm(xr, (C,), gamma, beta, 1e-6).reshape(n, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5)
+    r2.reshape(n * (H // 2) * (W // 2), 4 * C).backward(dyp.float())
+    _close(dx, xr.grad, 2e-2, 2e-2)
+
+
+def test_elementwise_and_casts(dev):
+    from mmgclip import kernels as K
+    x = _r((1000, 64), dev, 9, 2.0)
+    xb = K.cast_bf16(x)
+    assert torch.equal(xb, x.to(BF))
+    assert torch.equal(K.cast_f32(xb), xb.float())
+    _close(K.gelu(xb), F.gelu(xb.float()), 1e-2, 1e-2)
+    w = _r((96, 384), dev, 10)
+    rs = _r((96,), dev, 11)
+    assert torch.equal(K.transpose_cast_bf16(w), w.t().contiguous().to(BF))
+    assert torch.equal(K.transpose_cast_bf16(w, rs), (w * rs[:, None]).t().contiguous().to(BF))
+
+
+def test_avgpool(dev):
+    from mmgclip import kernels as K
+    n, HW, C = 3, 1024, 768
+    x = _r((n * HW, C), dev, 12).to(BF)
+    y = K.avgpool_fwd(x, n, HW, C)
+    _close(y, x.float().reshape(n, HW, C).mean(1), 1e-4, 1e-4)
+    dy = _r((n, C), dev, 13)
+    dx = K.avgpool_bwd(dy, n, HW, C)
+    _close(dx, (dy / HW)[:, None, :].expand(n, HW, C).reshape(n * HW, C), 1e-2, 1e-6)
+
+
+def test_patchify_matches_conv_unfold(dev):
+    from mmgclip import kernels as K
+    img = torch.rand(2, 1, 32, 48, generator=torch.Generator().manual_seed(14)).to(dev)
+    p = K.patchify(img, 4, 32, True)
+    scaled = (img * 65535.0 - 32767.5) / 32767.5
+    ref = scaled.reshape(2, 1, 8, 4, 12, 4).permute(0, 2, 4, 3, 5, 1).reshape(2 * 8 * 12, 16)
+    _close(p[:, :16], ref, 1e-2, 1e-2)
+    assert (p[:, 16:] == 0).all()
+
+
+def test_adamw_matches_torch(dev):
+    from mmgclip import kernels as K
+    p0 = _r((5000,), dev, 15)
+    p = p0.clone()
+    tp = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([tp], lr=5e-5, weight_decay=1e-4)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    p16 = torch.empty(5000, device=dev, dtype=BF)
+    for step in range(1, 4):
+        g = _r((5000,), dev, 100 + step)
+        tp.grad = g.clone()
+        opt.step()
+        K.adamw_step(p, g, m, v, p16, 5e-5, 0.9, 0.999, 1e-8, 1e-4, step)
+    _close(p, tp.data, 1e-6, 1e-7)
+    assert torch.equal(p16, p.to(BF))
+
+
+@pytest.mark.parametrize("n,H,W,C", [(2, 32, 32, 96), (1, 56, 56, 96), (2, 14, 14, 384), (3, 7, 7, 768), (1, 64, 40, 192)])
+def test_dwconv7(dev, n, H, W, C):
+    from mmgclip import kernels as K
+    x = _r((n, H, W, C), dev, 16).to(BF)
+    w = _r((C, 1, 7, 7), dev, 17, 0.1)
+    b = _r((C,), dev, 18)
+    w49 = w.reshape(C, 49).t().contiguous()
+    y = K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, padding=3, groups=C)
+    _close(y.reshape(n, H, W, C), ref.permute(0, 2, 3, 1), 1e-2, 2e-2)
+    dy = _r((n, H, W, C), dev, 19).to(BF)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    res = _r((n * H * W, C), dev, 20).to(BF)
+    dx = K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True)
+    _close(dx.reshape(n, H, W, C), xr.grad.permute(0, 2, 3, 1) + res.float().reshape(n, H, W, C), 1e-2, 3e-2)
+    dw, db = torch.zeros(49, C, device=dev), torch.zeros(C, device=dev)
+    K.dwconv7_wgrad(x.reshape(-1, C), dy.reshape(-1, C), dw, db, n, H, W, C)
+    _close(dw, wr.grad.reshape(C, 49).t(), 2e-3, 2e-3 * (n * H * W) ** 0.5)
+    _close(db, br.grad, 2e-3, 2e-3 * (n * H * W) ** 0.5)
+
+
+def _attn_ref(qkv, mask, B, S, heads):
+    Hd = heads * 64
+    q, k, v = qkv.float().reshape(B, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * 0.125
+    if mask is not None:
+        s = s + (1.0 - mask.float())[:, None, None, :] * torch.finfo(torch.float32).min
+    p = s.softmax(-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * S, Hd)
+
+
+@pytest.mark.parametrize("B,S,heads", [(3, 77, 12), (2, 32, 2), (2, 128, 4), (1, 256, 2), (5, 19, 1)])
+def test_attention_fwd_bwd(dev, B, S, heads):
+    from mmgclip import kernels as K
+    Hd = heads * 64
+    qkv = _r((B * S, 3 * Hd), dev, 21).to(BF)
+    g = torch.Generator().manual_seed(22)
+    lens = torch.randint(max(1, S // 3), S + 1, (B,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S)[None, :] < lens[:, None]).long().to(dev)
+    ctx, lse = K.attention_fwd(qkv, mask, B, S, heads)
+    qr = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qr, mask, B, S, heads)
+    _close(ctx, ref, 2e-2, 2e-2)
+    dctx = _r((B * S, Hd), dev, 23).to(BF)
+    dqkv = K.attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads)
+    ref.backward(dctx.float())
+    _close(dqkv, qr.grad, 5e-2, 5e-2)
+
+
+def test_attention_fwd_long(dev):
+    from mmgclip import kernels as K
+    B, S, heads = 1, 512, 2
+    qkv = _r((B * S, 3 * heads * 64), dev, 24).to(BF)
+    ctx, _ = K.attention_fwd(qkv, None, B, S, heads, want_lse=False)
+    _close(ctx, _attn_ref(qkv, None, B, S, heads), 2e-2, 2e-2)
+
+
+def test_bert_embeddings_and_eos_pool(dev):
+    from mmgclip import kernels as K
+    B, S, H, V = 4, 77, 768, 1000
+    g = torch.Generator().manual_seed(25)
+    ids = torch.randint(0, V, (B, S), generator=g).to(dev)
+    tt = torch.randint(0, 2, (B, S), generator=g).to(dev)
+    word, pos, typ = _r((V, H), dev, 26).to(BF), _r((512, H), dev, 27).to(BF), _r((2, H), dev, 28).to(BF)
+    out = K.bert_embed_fwd(ids, tt, word, pos, typ, S)
+    ref = word.float()[ids] + pos.float()[:S][None] + typ.float()[tt]
+    _close(out, ref.reshape(B * S, H), 1e-2, 2e-2)
+    gr = _r((B * S, H), dev, 29).to(BF)
+    dword, dpos, dtyp = torch.zeros(V, H, device=dev), torch.zeros(512, H, device=dev), torch.zeros(2, H, device=dev)
+    K.bert_embed_bwd(gr, ids, tt, dword, dpos, dtyp, B, S)
+    rw = torch.zeros(V, H, device=dev).index_add_(0, ids.reshape(-1), gr.float())
+    rp = gr.float().reshape(B, S, H).sum(0)
+    rt = torch.zeros(2, H, device=dev).index_add_(0, tt.reshape(-1), gr.float())
+    _close(dword, rw, 1e-4, 1e-4)
+    _close(dpos[:S], rp, 1e-4, 1e-4)
+    assert (dpos[S:] == 0).all()
+    _close(dtyp, rt, 1e-4, 1e-3)
+    # EOS pooling
+    lens = torch.tensor([77, 8, 30, 1])
+    mask = (torch.arange(S)[None, :] < lens[:, None]).long().to(dev)
+    hid = _r((B * S, H), dev, 30).to(BF)
+    pooled, idx = K.eos_pool_fwd(hid, mask, B, S)
+    assert idx.cpu().tolist() == (lens - 1).tolist()
+    _close(pooled, hid.float().reshape(B, S, H)[torch.arange(B), lens - 1], 0, 0)
+    dp = _r((B, H), dev, 31)
+    dh = K.eos_pool_bwd(dp, idx, B, S).float().reshape(B, S, H)
+    ref = torch.zeros(B, S, H, device=dev)
+    ref[torch.arange(B), lens - 1] = dp.to(BF).float()
+    assert torch.equal(dh, ref)
