@@ -119,6 +119,8 @@ int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const fl
 
 /* y = GELU(x) elementwise, bf16, n % 8 == 0 (rebuilds the FFN activation in the backward pass). */
 int mmg_gelu_fwd_bf16(const void* x, void* y, long long n, mmg_stream_t stream);
+/* out = dy * act'(pre) elementwise, bf16; kind 0 = GELU(erf), 1 = ReLU; n % 8 == 0. */
+int mmg_act_grad_bf16(const void* dy, const void* pre, void* out, long long n, int kind, mmg_stream_t stream);
 /* dtype conversions of flat buffers */
 int mmg_cast_f32_bf16(const float* x, void* y, long long n, mmg_stream_t stream);
 int mmg_cast_bf16_f32(const void* x, float* y, long long n, mmg_stream_t stream);
@@ -140,6 +142,20 @@ int mmg_patchify(const float* img, void* out, int n, int Cin, int H, int W, int 
  * p_bf16 (nullable) receives the refreshed bf16 working copy.  step counts from 1. */
 int mmg_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale, mmg_stream_t stream);
+
+/* ConvNeXt layer scale (out = x + gamma * (G W2^T + b2)): converts the unscaled weight-gradient GEMM results
+ * dW2raw [C,K], db2raw [C] into dgamma, dW2, db2 (all ACCUMULATED).  torchvision CNBlock.layer_scale. */
+int mmg_layerscale_finalize(const float* W2, const float* b2, const float* gamma, const float* dW2raw,
+                            const float* db2raw, float* dW2, float* db2, float* dgamma, int C, int K,
+                            mmg_stream_t stream);
+/* dst += relayout(src): mode 0 = [R,(kh,kw,ci)] -> [R,CI,KH,KW] (patchify-conv weight gradients),
+ * mode 1 = [49,R] -> [R,49] (depthwise taps). */
+int mmg_grad_relayout(const float* src, float* dst, int mode, int R, int CI, int KH, int KW, int ld_src,
+                      mmg_stream_t stream);
+
+/* Inverted dropout on fp32 (projection heads: mmgclip/networks/projection.py:50,59,91,98); keep = uint8 mask. */
+int mmg_dropout_fwd(const float* x, float* y, void* keep, long long n, float p, long long seed, mmg_stream_t stream);
+int mmg_dropout_bwd(const float* dy, const void* keep, float* dx, long long n, float p, mmg_stream_t stream);
 
 /* ---- depthwise 7x7 convolution, NHWC bf16 (ConvNeXt CNBlock) ------------------------------------------------ */
 

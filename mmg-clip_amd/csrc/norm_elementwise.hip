@@ -440,3 +440,133 @@ MMG_API int mmg_adamw_step(float* p, const float* g, float* m, float* v, void* p
     MMG_LAUNCH_CHECK("mmg_adamw_step");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ConvNeXt layer scale: out = x + gamma * (G W2^T + b2).  The weight-gradient GEMM produces the UNSCALED
+// dW2raw = dOut^T G and db2raw = colsum(dOut); this kernel turns them into the true gradients (one wave per row c):
+//   dgamma[c] += <W2[c,:], dW2raw[c,:]> + b2[c] * db2raw[c] ;  dW2[c,:] += gamma[c] * dW2raw[c,:] ;  db2[c] += gamma[c] * db2raw[c]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layerscale_finalize_kernel(const float* __restrict__ W2, const float* __restrict__ b2,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ dW2raw,
+                                                                  const float* __restrict__ db2raw, float* __restrict__ dW2,
+                                                                  float* __restrict__ db2, float* __restrict__ dgamma, int C,
+                                                                  int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    const float gm = gamma[c];
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float r = dW2raw[(size_t)c * K + k];
+        s += W2[(size_t)c * K + k] * r;
+        dW2[(size_t)c * K + k] += gm * r;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        dgamma[c] += s + b2[c] * db2raw[c];
+        db2[c] += gm * db2raw[c];
+    }
+}
+MMG_API int mmg_layerscale_finalize(const float* W2, const float* b2, const float* gamma, const float* dW2raw,
+                                    const float* db2raw, float* dW2, float* db2, float* dgamma, int C, int K,
+                                    hipStream_t stream) {
+    MMG_CHECK_ARG(W2 && b2 && gamma && dW2raw && db2raw && dW2 && db2 && dgamma && C > 0 && K > 0,
+                  "mmg_layerscale_finalize: bad argument");
+    hipLaunchKernelGGL(layerscale_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, W2, b2, gamma, dW2raw, db2raw, dW2,
+                       db2, dgamma, C, K);
+    MMG_LAUNCH_CHECK("mmg_layerscale_finalize");
+    return 0;
+}
+
+// dst[i] += src[perm(i)] for the small layout changes between GEMM-shaped gradients and torch's conv layouts:
+//   mode 0: src [R, KH*KW*CI] (kh,kw,ci fastest) -> dst [R, CI, KH, KW]     (patchify convolutions)
+//   mode 1: src [49, C]                          -> dst [C, 49]             (depthwise taps)
+__global__ __launch_bounds__(256) void grad_relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, int mode,
+                                                            int R, int CI, int KH, int KW, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (mode == 0) {
+            const int kw = (int)(i % KW), kh = (int)((i / KW) % KH), ci = (int)((i / ((size_t)KW * KH)) % CI);
+            const size_t r = i / ((size_t)KW * KH * CI);
+            dst[i] += src[r * ((size_t)KH * KW * CI) + ((size_t)kh * KW + kw) * CI + ci];
+        } else {
+            const int k = (int)(i % 49);
+            const size_t c = i / 49;
+            dst[i] += src[(size_t)k * R + c];
+        }
+    }
+}
+MMG_API int mmg_grad_relayout(const float* src, float* dst, int mode, int R, int CI, int KH, int KW, int ld_src,
+                              hipStream_t stream) {
+    MMG_CHECK_ARG(src && dst && (mode == 0 || mode == 1) && R > 0, "mmg_grad_relayout: bad argument");
+    MMG_CHECK_ARG(mode == 1 || ld_src == KH * KW * CI, "mmg_grad_relayout: ld_src=%d must equal KH*KW*CI", ld_src);
+    const size_t n = mode == 0 ? (size_t)R * CI * KH * KW : (size_t)R * 49;
+    int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(grad_relayout_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, mode, R, CI, KH, KW, n);
+    MMG_LAUNCH_CHECK("mmg_grad_relayout");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dropout for the projection heads (MultiLinearHead / MLPProjectionHead, mmgclip/networks/projection.py:50,59,91,98).
+// Counter-based generator (one 64-bit splitmix round per element, keyed by seed): reproducible for a seed, not
+// bit-compatible with torch's Philox stream (parity runs use p = 0, SURVEY.md §7 "Hard parts").
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          unsigned char* __restrict__ keep, size_t n, float p,
+                                                          unsigned long long seed) {
+    const float inv = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float u = (float)(splitmix64(seed ^ (i * 0xD1342543DE82EF95ull)) >> 40) * (1.0f / 16777216.0f);
+        const unsigned char k = u >= p;
+        keep[i] = k;
+        y[i] = k ? x[i] * inv : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ keep,
+                                                          float* __restrict__ dx, size_t n, float p) {
+    const float inv = 1.0f / (1.0f - p);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = keep[i] ? dy[i] * inv : 0.f;
+}
+MMG_API int mmg_dropout_fwd(const float* x, float* y, void* keep, long long n, float p, long long seed, hipStream_t stream) {
+    MMG_CHECK_ARG(x && y && keep && n > 0 && p >= 0.f && p < 1.f, "mmg_dropout_fwd: bad argument (p=%f)", p);
+    int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, y, (unsigned char*)keep, (size_t)n, p,
+                       (unsigned long long)seed);
+    MMG_LAUNCH_CHECK("mmg_dropout_fwd");
+    return 0;
+}
+MMG_API int mmg_dropout_bwd(const float* dy, const void* keep, float* dx, long long n, float p, hipStream_t stream) {
+    MMG_CHECK_ARG(dy && dx && keep && n > 0 && p >= 0.f && p < 1.f, "mmg_dropout_bwd: bad argument");
+    int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, (const unsigned char*)keep, dx, (size_t)n, p);
+    MMG_LAUNCH_CHECK("mmg_dropout_bwd");
+    return 0;
+}
+
+// out = dy * act'(pre) elementwise (bf16), kind 0 = GELU(erf), 1 = ReLU; n % 8 == 0
+__global__ __launch_bounds__(256) void act_grad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ pre,
+                                                       bf16_t* __restrict__ out, size_t nvec, int kind) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        float g[8], h[8];
+        unpack8(reinterpret_cast<const uint4*>(dy)[i], g);
+        unpack8(reinterpret_cast<const uint4*>(pre)[i], h);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = kind == 0 ? g[e] * gelu_grad_f(h[e]) : (h[e] > 0.f ? g[e] : 0.f);
+        reinterpret_cast<uint4*>(out)[i] = pack8(g);
+    }
+}
+MMG_API int mmg_act_grad_bf16(const void* dy, const void* pre, void* out, long long n, int kind, hipStream_t stream) {
+    MMG_CHECK_ARG(dy && pre && out && n > 0 && n % 8 == 0 && (kind == 0 || kind == 1), "mmg_act_grad_bf16: bad argument");
+    const size_t nvec = (size_t)n / 8;
+    int blocks = (int)((nvec + 255) / 256 > 8192 ? 8192 : (nvec + 255) / 256);
+    hipLaunchKernelGGL(act_grad_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)pre, (bf16_t*)out, nvec, kind);
+    MMG_LAUNCH_CHECK("mmg_act_grad_bf16");
+    return 0;
+}

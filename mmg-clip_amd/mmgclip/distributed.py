@@ -1,0 +1,90 @@
+"""Data-parallel plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI; "gloo" in the
+CPU tests).  The reference has no multi-GPU path; this is the §8(e) design:
+
+  exchange 1  all-gather of the L2-normalised image / text embeddings ([n_local, D] each)
+  exchange 2  all-gather of the two log-sum-exp vectors (so embedding gradients are complete locally; no N x D
+              reduce-scatter, no autograd through a collective)
+  exchange 3  SUM all-reduce of the parameter gradients: one flat buffer per tower arena + one coalesced buffer for
+              the small leftovers, issued on a side stream as soon as each tower's backward has finished so the
+              ConvNeXt all-reduce overlaps the BERT backward.
+The fused loss already carries the 1/(2N) factor of the GLOBAL mean, so gradients are summed, not averaged.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+
+    def all_gather_rows(self, t):
+        """[n, ...] -> [world*n, ...] in rank order (no autograd: gradients are formed locally, see head.FusedClipLoss)."""
+        t = t.contiguous()
+        out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment; returns Comm or None when WORLD_SIZE <= 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return Comm()
+
+
+class GradSync:
+    """SUM all-reduce of parameter gradients, arena by arena, overlapped with the remaining backward work."""
+
+    def __init__(self, comm, arenas=(), extra_params=()):
+        self.comm = comm
+        self.arenas = [a for a in arenas if a is not None]
+        self.extra = [p for p in extra_params]
+        self.side = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self._pending = []
+
+    def reduce_arena_async(self, arena):
+        """Call when this arena's backward has been enqueued on the current stream."""
+        if self.comm is None or self.comm.world_size == 1:
+            return
+        if self.side is None:
+            self.comm.all_reduce_sum(arena.grad)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.comm.all_reduce_sum(arena.grad)
+            done = torch.cuda.Event()
+            done.record()
+        self._pending.append(done)
+
+    def finish(self):
+        """Reduce the leftovers (projection heads, logit_scale) as ONE coalesced buffer and join the side stream."""
+        if self.comm is None or self.comm.world_size == 1:
+            return
+        grads = [p.grad for p in self.extra if p.grad is not None]
+        if grads:
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            self.comm.all_reduce_sum(flat)
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        for ev in self._pending:
+            torch.cuda.current_stream().wait_event(ev)
+        self._pending.clear()

@@ -1,0 +1,275 @@
+"""BERT text tower on the HIP kernels (forward + backward), state-dict compatible with Hugging Face `BertModel`.
+
+Reference: `BertEncoder` wraps `AutoModel.from_pretrained(<name>)` and returns `last_hidden_state`
+(mmgclip/networks/encoder.py:131-156); architecture values from notebooks/bert_experimental.ipynb:609-624
+(vocab 28996, hidden 768, 12 layers x 12 heads, FFN 3072, 512 positions, LayerNorm eps 1e-12, erf-GELU, post-LN).
+The reference freezes every BERT parameter (encoder.py:141-142); `freeze=False` enables the north star's fine-tuning.
+Dropout (p = 0.1 in the HF config, live because the reference calls model.train()) is NOT applied here: parity is
+defined for eval()/p = 0 (SURVEY.md §0, §7 "Hard parts").
+
+Device layout: hidden states bf16 [B*S, 768]; Q, K, V come from ONE fused GEMM ([2304, 768] weight = the three HF
+matrices stacked, contiguous in the parameter arena so its gradient needs no scatter).
+"""
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from .. import kernels as K
+from .. import linalg as L
+from ..params import ParamArena
+
+
+class BertConfigLite:
+    """The subset of HF BertConfig the tower needs (defaults = Bio_ClinicalBERT, notebooks/bert_experimental.ipynb:609-624)."""
+
+    def __init__(self, vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                 initializer_range=0.02, **_):
+        self.vocab_size, self.hidden_size = vocab_size, hidden_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.max_position_embeddings = intermediate_size, max_position_embeddings
+        self.type_vocab_size, self.layer_norm_eps, self.initializer_range = type_vocab_size, layer_norm_eps, initializer_range
+        assert hidden_size == 64 * num_attention_heads, "the attention kernel is specialised for head_dim 64"
+
+
+def _hf_layout(cfg):
+    """Module tree whose state-dict keys equal Hugging Face BertModel's (incl. the unused pooler)."""
+    H, F = cfg.hidden_size, cfg.intermediate_size
+    m = nn.Module()
+    m.embeddings = nn.Module()
+    m.embeddings.word_embeddings = nn.Embedding(cfg.vocab_size, H, padding_idx=0)
+    m.embeddings.position_embeddings = nn.Embedding(cfg.max_position_embeddings, H)
+    m.embeddings.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, H)
+    m.embeddings.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+    m.encoder = nn.Module()
+    layers = []
+    for _ in range(cfg.num_hidden_layers):
+        lyr = nn.Module()
+        lyr.attention = nn.Module()
+        lyr.attention.self = nn.Module()
+        lyr.attention.self.query, lyr.attention.self.key, lyr.attention.self.value = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
+        lyr.attention.output = nn.Module()
+        lyr.attention.output.dense = nn.Linear(H, H)
+        lyr.attention.output.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+        lyr.intermediate = nn.Module()
+        lyr.intermediate.dense = nn.Linear(H, F)
+        lyr.output = nn.Module()
+        lyr.output.dense = nn.Linear(F, H)
+        lyr.output.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+        layers.append(lyr)
+    m.encoder.layer = nn.ModuleList(layers)
+    m.pooler = nn.Module()
+    m.pooler.dense = nn.Linear(H, H)
+    for mod in m.modules():                               # HF _init_weights
+        if isinstance(mod, nn.Linear):
+            nn.init.normal_(mod.weight, std=cfg.initializer_range)
+            nn.init.zeros_(mod.bias)
+        elif isinstance(mod, nn.Embedding):
+            nn.init.normal_(mod.weight, std=cfg.initializer_range)
+            if mod.padding_idx is not None:
+                with torch.no_grad():
+                    mod.weight[mod.padding_idx].zero_()
+    return m
+
+
+class BertTower(nn.Module):
+    def __init__(self, config=None, micro_batch=4096):
+        super().__init__()
+        self.config = config or BertConfigLite()
+        self.model = _hf_layout(self.config)
+        self.model.config = self.config
+        self.model_output_dimension = self.config.hidden_size
+        self.micro_batch = micro_batch        # sequences per pass
+        self._arena = None
+        self._wc = None
+        self._wc_version = None
+        self._anchor = None
+
+    # ---- parameter plumbing: arena order puts q,k,v (weights, then biases) of a layer next to each other -----
+    def _ordered_named_parameters(self):
+        named = dict(self.model.named_parameters())
+        order = [n for n in named if n.startswith("embeddings.")]
+        for i in range(self.config.num_hidden_layers):
+            p = f"encoder.layer.{i}."
+            order += [p + f"attention.self.{x}.weight" for x in ("query", "key", "value")]
+            order += [p + f"attention.self.{x}.bias" for x in ("query", "key", "value")]
+            order += [n for n in named if n.startswith(p) and ".attention.self." not in n]
+        order += [n for n in named if n.startswith("pooler.")]
+        assert len(order) == len(named)
+        return [(n, named[n]) for n in order]
+
+    def _materialize(self, device):
+        if self._arena is not None and self._arena.device == device and self._arena.is_bound():
+            return
+        self._arena = ParamArena(self._ordered_named_parameters(), device)
+        self._wc_version = None
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+
+    @property
+    def arena(self):
+        return self._arena
+
+    def _refresh_working_copies(self):
+        A = self._arena
+        v = A.version()
+        if self._wc_version == v:
+            return
+        H = self.config.hidden_size
+        wc = {}
+        e = self.model.embeddings
+        wc["word"], wc["pos"], wc["type"] = (K.cast_bf16(e.word_embeddings.weight.data), K.cast_bf16(e.position_embeddings.weight.data),
+                                             K.cast_bf16(e.token_type_embeddings.weight.data))
+        for i, lyr in enumerate(self.model.encoder.layer):
+            p = f"encoder.layer.{i}."
+            wqkv = A.span(p + "attention.self.query.weight", p + "attention.self.value.weight")[:3 * H * H].view(3 * H, H)
+            wc[f"{i}.wqkv"] = K.cast_bf16(wqkv)
+            wc[f"{i}.wqkvt"] = K.transpose_cast_bf16(wqkv)
+            wc[f"{i}.bqkv"] = A.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
+            for tag, lin in (("wo", lyr.attention.output.dense), ("wi", lyr.intermediate.dense), ("wf", lyr.output.dense)):
+                wc[f"{i}.{tag}"] = K.cast_bf16(lin.weight.data)
+                wc[f"{i}.{tag}t"] = K.transpose_cast_bf16(lin.weight.data)
+        self._wc, self._wc_version = wc, v
+
+    def _check_qkv_contiguous(self):
+        H = self.config.hidden_size
+        A = self._arena
+        assert (H * H) % 64 == 0 and H % 64 == 0, "fused QKV views need 64-element aligned slices"
+        for i in range(self.config.num_hidden_layers):
+            p = f"encoder.layer.{i}.attention.self."
+            assert A.offsets[p + "key.weight"] - A.offsets[p + "query.weight"] == H * H
+            assert A.offsets[p + "key.bias"] - A.offsets[p + "query.bias"] == H
+
+    # ---- one micro-batch ---------------------------------------------------------------------------------------
+    def _forward_mb(self, ids, tt, mask, save):
+        cfg, wc = self.config, self._wc
+        B, S = ids.shape
+        heads, eps = cfg.num_attention_heads, cfg.layer_norm_eps
+        e = self.model.embeddings
+        emb = K.bert_embed_fwd(ids, tt, wc["word"], wc["pos"], wc["type"], S)
+        x, mean, rstd = K.layernorm_fwd(emb, e.LayerNorm.weight.data, e.LayerNorm.bias.data, eps, want_stats=save)
+        saved = {"emb": (emb, mean, rstd), "layers": [], "shape": (B, S), "tok": (ids, tt, mask)} if save else None
+        for i, lyr in enumerate(self.model.encoder.layer):
+            qkv = L.gemm_nt(x, wc[f"{i}.wqkv"], bias=wc[f"{i}.bqkv"][:3 * cfg.hidden_size])
+            ctx, lse = K.attention_fwd(qkv, mask, B, S, heads, want_lse=save)
+            a = L.gemm_nt(ctx, wc[f"{i}.wo"], bias=lyr.attention.output.dense.bias.data, residual=x)
+            x1, m1, r1 = K.layernorm_fwd(a, lyr.attention.output.LayerNorm.weight.data, lyr.attention.output.LayerNorm.bias.data,
+                                         eps, want_stats=save)
+            hpre = torch.empty(x.shape[0], cfg.intermediate_size, device=x.device, dtype=torch.bfloat16) if save else None
+            g = L.gemm_nt(x1, wc[f"{i}.wi"], bias=lyr.intermediate.dense.bias.data, epi=L.EPI_GELU, aux_out=hpre)
+            f = L.gemm_nt(g, wc[f"{i}.wf"], bias=lyr.output.dense.bias.data, residual=x1)
+            x2, m2, r2 = K.layernorm_fwd(f, lyr.output.LayerNorm.weight.data, lyr.output.LayerNorm.bias.data, eps, want_stats=save)
+            if save:
+                saved["layers"].append((x, qkv, ctx, lse, a, m1, r1, x1, hpre, f, m2, r2))
+            x = x2
+        return x, saved
+
+    def _backward_mb(self, dx, saved):
+        cfg, wc, A = self.config, self._wc, self._arena
+        B, S = saved["shape"]
+        ids, tt, mask = saved["tok"]
+        heads, H = cfg.num_attention_heads, cfg.hidden_size
+        for i in range(cfg.num_hidden_layers - 1, -1, -1):
+            lyr = self.model.encoder.layer[i]
+            p = f"encoder.layer.{i}."
+            x, qkv, ctx, lse, a, m1, r1, x1, hpre, f, m2, r2 = saved["layers"][i]
+            df = K.layernorm_bwd(dx, f, m2, r2, lyr.output.LayerNorm.weight.data, A.g(p + "output.LayerNorm.weight"),
+                                 A.g(p + "output.LayerNorm.bias"))
+            g = K.gelu(hpre)
+            L.gemm_tn_acc(df, g, A.g(p + "output.dense.weight"))
+            L.colsum_acc(df, A.g(p + "output.dense.bias"))
+            del g
+            dh = L.gemm_nt(df, wc[f"{i}.wft"], epi=L.EPI_DGELU, aux_in=hpre)
+            L.gemm_tn_acc(dh, x1, A.g(p + "intermediate.dense.weight"))
+            L.colsum_acc(dh, A.g(p + "intermediate.dense.bias"))
+            dx1 = L.gemm_nt(dh, wc[f"{i}.wit"], residual=df)          # + residual path of the FFN block
+            del dh, df
+            da = K.layernorm_bwd(dx1, a, m1, r1, lyr.attention.output.LayerNorm.weight.data,
+                                 A.g(p + "attention.output.LayerNorm.weight"), A.g(p + "attention.output.LayerNorm.bias"))
+            del dx1
+            L.gemm_tn_acc(da, ctx, A.g(p + "attention.output.dense.weight"))
+            L.colsum_acc(da, A.g(p + "attention.output.dense.bias"))
+            dctx = L.gemm_nt(da, wc[f"{i}.wot"])
+            dqkv = K.attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads)
+            del dctx
+            gw = A.gspan(p + "attention.self.query.weight", p + "attention.self.value.weight")[:3 * H * H].view(3 * H, H)
+            gb = A.gspan(p + "attention.self.query.bias", p + "attention.self.value.bias")[:3 * H]
+            L.gemm_tn_acc(dqkv, x, gw)
+            L.colsum_acc(dqkv, gb)
+            dx = L.gemm_nt(dqkv, wc[f"{i}.wqkvt"], residual=da)       # + residual path of the attention block
+            del dqkv, da
+            saved["layers"][i] = None
+        emb, mean, rstd = saved["emb"]
+        e = self.model.embeddings
+        demb = K.layernorm_bwd(dx, emb, mean, rstd, e.LayerNorm.weight.data, A.g("embeddings.LayerNorm.weight"),
+                               A.g("embeddings.LayerNorm.bias"))
+        K.bert_embed_bwd(demb, ids, tt, A.g("embeddings.word_embeddings.weight"), A.g("embeddings.position_embeddings.weight"),
+                         A.g("embeddings.token_type_embeddings.weight"), B, S)
+
+    # ---- public -----------------------------------------------------------------------------------------------------
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, **_):
+        """-> last_hidden_state as bf16 [B*S, H] (use .view(B, S, H).float() for the HF-shaped tensor)."""
+        _hip.require_gpu(input_ids)
+        self._materialize(input_ids.device)
+        self._check_qkv_contiguous()
+        ids = input_ids.to(torch.int64).contiguous()
+        mask = attention_mask.to(torch.int64).contiguous() if attention_mask is not None else None
+        tt = token_type_ids.to(torch.int64).contiguous() if token_type_ids is not None else None
+        if ids.shape[1] > self.config.max_position_embeddings:
+            raise ValueError(f"sequence length {ids.shape[1]} exceeds max_position_embeddings")
+        needs_grad = torch.is_grad_enabled() and self._arena.any_trainable()
+        return _BertFn.apply(self, ids, tt, mask, self._anchor if needs_grad else None)
+
+
+class _BertFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tower, ids, tt, mask, anchor):
+        tower._refresh_working_copies()
+        save = anchor is not None
+        outs, saved = [], []
+        mb = tower.micro_batch
+        for i in range(0, ids.shape[0], mb):
+            sl = slice(i, i + mb)
+            h, sv = tower._forward_mb(ids[sl], tt[sl] if tt is not None else None, mask[sl] if mask is not None else None, save)
+            outs.append(h)
+            saved.append(sv)
+        ctx.tower, ctx.saved_mb = tower, saved if save else None
+        out = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        tower = ctx.tower
+        tower._arena.prepare_grads()
+        dh = dh.to(torch.bfloat16).contiguous()
+        row = 0
+        for sv in ctx.saved_mb:
+            B, S = sv["shape"]
+            tower._backward_mb(dh[row:row + B * S], sv)
+            row += B * S
+        ctx.saved_mb = None
+        return None, None, None, None, None
+
+
+class EosPool(torch.autograd.Function):
+    """text_features = hidden[arange(n), attention_mask.sum(-1) - 1]  (mmgclip_model.py:110-111); fp32 [B, H]."""
+
+    @staticmethod
+    def forward(ctx, hidden, mask, B, S):
+        out, idx = K.eos_pool_fwd(hidden, mask.to(torch.int64).contiguous(), B, S)
+        ctx.save_for_backward(idx)
+        ctx.B, ctx.S = B, S
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return K.eos_pool_bwd(dout.float().contiguous(), idx, ctx.B, ctx.S), None, None, None
+
+
+def hf_config_dict(cfg):
+    return dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                layer_norm_eps=cfg.layer_norm_eps, hidden_act="gelu", hidden_dropout_prob=0.0,
+                attention_probs_dropout_prob=0.0, initializer_range=cfg.initializer_range, pad_token_id=0,
+                position_embedding_type="absolute", model_type="bert")

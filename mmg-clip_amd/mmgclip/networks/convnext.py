@@ -1,0 +1,291 @@
+"""ConvNeXt image tower on the HIP kernels: forward + backward over NHWC bf16 activations.
+
+What the reference has (path:line in the reference tree): `ConvNextTiny.forward` = `model.features(x)` then
+`model.avgpool(x)` on a torchvision-layout ConvNeXt-T TorchScript archive (mmgclip/networks/encoder.py:40-55), fed by
+`(x*65535 - 32767.5)/32767.5` (mmgclip/networks/image_features.py:95-99); module tree printed in
+notebooks/clf_convnext_tiny_experimental.ipynb cell 3 (Conv2dNormActivation(Conv2d 4x4/4, LayerNorm2d), CNBlock(dwconv7,
+Permute, LayerNorm, Linear C->4C, GELU, Linear 4C->C, Permute) * layer_scale + residual, depths 3/3/9/3, dims
+96/192/384/768; downsample = LayerNorm2d + Conv2d 2x2/2).  The reference never trains it; the backward here is new
+capability (north star) and is checked against oracle/encoders_oracle.py.
+
+Parameter names/shapes follow torchvision (`features.{i}.{j}.block.{k}.weight`, `layer_scale` ...) so a torchvision
+state dict loads unchanged.  Stochastic depth is not applied (p = 0).
+
+Data layout on the MI355X: activations are bf16 [n*H*W, C] (NHWC flattened), so every pointwise Linear is a plain
+row-major GEMM and LayerNorm reads contiguous rows; the 2x2/4x4 stride=kernel convolutions become GEMMs on patchified
+rows (the LayerNorm kernel writes the patchified layout directly).  Saved for backward per block and pixel: block input
+(C), depthwise output (C), pre-GELU hidden (4C) in bf16 + LN statistics; LN output and GELU output are rebuilt.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from .. import kernels as K
+from .. import linalg as L
+from ..params import ParamArena
+
+CONFIGS = {
+    "tiny": dict(depths=(3, 3, 9, 3), dims=(96, 192, 384, 768)),
+    "small": dict(depths=(3, 3, 27, 3), dims=(96, 192, 384, 768)),
+    "base": dict(depths=(3, 3, 27, 3), dims=(128, 256, 512, 1024)),
+}
+LN_EPS = 1e-6
+
+
+class LayerNorm2d(nn.LayerNorm):
+    """Parameter container with torchvision's name; the arithmetic runs in mmg_layernorm_fwd."""
+
+
+class CNBlock(nn.Module):
+    def __init__(self, dim, layer_scale=1e-6):
+        super().__init__()
+        self.block = nn.Sequential(
+            nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim, bias=True),
+            nn.Identity(),                      # Permute([0, 2, 3, 1])
+            nn.LayerNorm(dim, eps=LN_EPS),
+            nn.Linear(dim, 4 * dim, bias=True),
+            nn.GELU(),
+            nn.Linear(4 * dim, dim, bias=True),
+            nn.Identity(),                      # Permute([0, 3, 1, 2])
+        )
+        self.layer_scale = nn.Parameter(torch.ones(dim, 1, 1) * layer_scale)
+
+
+def build_features(variant="tiny", in_chans=1):
+    cfg = CONFIGS[variant]
+    dims, depths = cfg["dims"], cfg["depths"]
+    layers = [nn.Sequential(nn.Conv2d(in_chans, dims[0], kernel_size=4, stride=4, bias=True), LayerNorm2d(dims[0], eps=LN_EPS))]
+    for i, (d, n) in enumerate(zip(dims, depths)):
+        layers.append(nn.Sequential(*[CNBlock(d) for _ in range(n)]))
+        if i < 3:
+            layers.append(nn.Sequential(LayerNorm2d(d, eps=LN_EPS), nn.Conv2d(d, dims[i + 1], kernel_size=2, stride=2)))
+    feats = nn.Sequential(*layers)
+    for m in feats.modules():                       # torchvision ConvNeXt init
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+    return feats
+
+
+class _TorchvisionLayout(nn.Module):
+    """`.features` / `.avgpool` holder so state-dict keys read `model.features...` like the reference archive."""
+
+    def __init__(self, variant, in_chans):
+        super().__init__()
+        self.features = build_features(variant, in_chans)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+
+
+class ConvNextTower(nn.Module):
+    """pixels fp32 [n, Cin, H, W] in [0,1] (scale16=True applies the reference's 16-bit scaling) -> features [n, dims[-1]]."""
+
+    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=16):
+        super().__init__()
+        self.variant, self.in_chans, self.scale16, self.micro_batch = variant, in_chans, scale16, micro_batch
+        self.dims, self.depths = CONFIGS[variant]["dims"], CONFIGS[variant]["depths"]
+        self.model = _TorchvisionLayout(variant, in_chans)
+        self.model_output_dimension = self.dims[-1]
+        self.kp = (16 * in_chans + 31) // 32 * 32          # stem GEMM K padded to the MFMA k-step
+        self._arena = None
+        self._wc = None
+        self._wc_version = None
+        self._anchor = None
+
+    # ---- parameter plumbing ------------------------------------------------------------------------------
+    def _materialize(self, device):
+        if self._arena is not None and self._arena.device == device and self._arena.is_bound():
+            return
+        self._arena = ParamArena(list(self.model.named_parameters()), device)
+        self._wc_version = None
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+
+    @property
+    def arena(self):
+        return self._arena
+
+    def _refresh_working_copies(self):
+        """bf16 / transposed / tap-major copies the kernels read; rebuilt only when a parameter changed."""
+        A = self._arena
+        v = A.version()
+        if self._wc_version == v:
+            return
+        f = self.model.features
+        wc = {}
+        stem = f[0][0].weight.data                                   # [C0, Cin, 4, 4] -> [(kh,kw,ci)] padded
+        w = torch.zeros(stem.shape[0], self.kp, device=stem.device)
+        w[:, :16 * self.in_chans] = stem.permute(0, 2, 3, 1).reshape(stem.shape[0], -1)
+        wc["stem.w"] = K.cast_bf16(w)
+        for si in range(4):
+            for bi, blk in enumerate(f[1 + 2 * si]):
+                C = self.dims[si]
+                key = f"{si}.{bi}"
+                wc[key + ".w49"] = blk.block[0].weight.data.reshape(C, 49).t().contiguous()
+                wc[key + ".w1"] = K.cast_bf16(blk.block[3].weight.data)                      # [4C, C]
+                wc[key + ".w1t"] = K.transpose_cast_bf16(blk.block[3].weight.data)           # [C, 4C]
+                wc[key + ".w2"] = K.cast_bf16(blk.block[5].weight.data)                      # [C, 4C]
+                wc[key + ".w2gt"] = K.transpose_cast_bf16(blk.block[5].weight.data,          # [4C, C] * gamma
+                                                          blk.layer_scale.data.reshape(C))
+            if si < 3:
+                conv = f[2 + 2 * si][1].weight.data                                          # [2C, C, 2, 2]
+                wds = conv.permute(0, 2, 3, 1).reshape(conv.shape[0], -1).contiguous()       # [(kh,kw,ci)]
+                wc[f"ds{si}.w"] = K.cast_bf16(wds)
+                wc[f"ds{si}.wt"] = K.transpose_cast_bf16(wds)
+        self._wc, self._wc_version = wc, v
+
+    # ---- forward / backward over one micro-batch -----------------------------------------------------------
+    def _forward_mb(self, img, save):
+        f, wc = self.model.features, self._wc
+        n, _, H, W = img.shape
+        h, w_ = H // 4, W // 4
+        saved = {}
+        p0 = K.patchify(img, 4, self.kp, self.scale16)
+        s0 = L.gemm_nt(p0, wc["stem.w"], bias=f[0][0].bias.data)
+        x, mean, rstd = K.layernorm_fwd(s0, f[0][1].weight.data, f[0][1].bias.data, LN_EPS, want_stats=save)
+        if save:
+            saved["stem"] = (p0, s0, mean, rstd)
+        for si in range(4):
+            C = self.dims[si]
+            for bi, blk in enumerate(f[1 + 2 * si]):
+                key = f"{si}.{bi}"
+                d = K.dwconv7(x, wc[key + ".w49"], blk.block[0].bias.data, n, h, w_, C)
+                ln, mean, rstd = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=save)
+                hpre = torch.empty(x.shape[0], 4 * C, device=x.device, dtype=torch.bfloat16) if save else None
+                g = L.gemm_nt(ln, wc[key + ".w1"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre)
+                xn = L.gemm_nt(g, wc[key + ".w2"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
+                               residual=x)
+                if save:
+                    saved[key] = (x, d, mean, rstd, hpre)
+                del ln, g
+                x = xn
+            if si < 3:
+                lnm = f[2 + 2 * si][0]
+                ld, mean, rstd = K.layernorm_fwd(x, lnm.weight.data, lnm.bias.data, LN_EPS, patch_hw=(h, w_), want_stats=save)
+                xn = L.gemm_nt(ld, wc[f"ds{si}.w"], bias=f[2 + 2 * si][1].bias.data)
+                if save:
+                    saved[f"ds{si}"] = (x, mean, rstd, ld)
+                x = xn
+                h, w_ = h // 2, w_ // 2
+        feat = K.avgpool_fwd(x, n, h * w_, self.dims[-1])
+        saved["shape"] = (n, H, W)
+        return feat, saved
+
+    def _backward_mb(self, dfeat, saved, tmp):
+        f, wc, A = self.model.features, self._wc, self._arena
+        n, H, W = saved["shape"]
+        h, w_ = H // 32, W // 32
+        gname = lambda mod, leaf: A.g(self._pname[id(mod)] + "." + leaf)      # noqa: E731
+        dx = K.avgpool_bwd(dfeat, n, h * w_, self.dims[-1])
+        for si in range(3, -1, -1):
+            C = self.dims[si]
+            if si < 3:
+                x, mean, rstd, ld = saved[f"ds{si}"]
+                conv, lnm = f[2 + 2 * si][1], f[2 + 2 * si][0]
+                L.gemm_tn_acc(dx, ld, tmp[f"ds{si}.dw"])
+                L.colsum_acc(dx, gname(conv, "bias"))
+                dld = L.gemm_nt(dx, wc[f"ds{si}.wt"])
+                h, w_ = h * 2, w_ * 2
+                dx = K.layernorm_bwd(dld, x, mean, rstd, lnm.weight.data, gname(lnm, "weight"), gname(lnm, "bias"),
+                                     patch_hw=(h, w_))
+                del dld
+            for bi in range(self.depths[si] - 1, -1, -1):
+                blk = f[1 + 2 * si][bi]
+                key = f"{si}.{bi}"
+                x, d, mean, rstd, hpre = saved[key]
+                g = K.gelu(hpre)
+                L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"])
+                L.colsum_acc(dx, tmp[key + ".db2raw"])
+                del g
+                dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre)
+                ln, _, _ = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=False)
+                L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"))
+                L.colsum_acc(dh, gname(blk.block[3], "bias"))
+                del ln
+                dln = L.gemm_nt(dh, wc[key + ".w1t"])
+                del dh
+                dd = K.layernorm_bwd(dln, d, mean, rstd, blk.block[2].weight.data, gname(blk.block[2], "weight"),
+                                     gname(blk.block[2], "bias"))
+                del dln
+                K.dwconv7_wgrad(x, dd, tmp[key + ".dw49"], gname(blk.block[0], "bias"), n, h, w_, C)
+                dx = K.dwconv7(dd, wc[key + ".w49"], None, n, h, w_, C, add=dx, flip=True)
+                del dd
+        p0, s0, mean, rstd = saved["stem"]
+        ds0 = K.layernorm_bwd(dx, s0, mean, rstd, f[0][1].weight.data, gname(f[0][1], "weight"), gname(f[0][1], "bias"))
+        L.gemm_tn_acc(ds0, p0, tmp["stem.dw"])
+        L.colsum_acc(ds0, gname(f[0][0], "bias"))
+
+    def _alloc_tmp(self, device):
+        z = lambda *s: torch.zeros(*s, device=device, dtype=torch.float32)   # noqa: E731
+        tmp = {"stem.dw": z(self.dims[0], self.kp)}
+        for si in range(4):
+            C = self.dims[si]
+            for bi in range(self.depths[si]):
+                key = f"{si}.{bi}"
+                tmp[key + ".dw2raw"], tmp[key + ".db2raw"], tmp[key + ".dw49"] = z(C, 4 * C), z(C), z(49, C)
+            if si < 3:
+                tmp[f"ds{si}.dw"] = z(self.dims[si + 1], 4 * C)
+        return tmp
+
+    def _finalize_grads(self, tmp):
+        """Fold GEMM-shaped temporaries into the torch-layout gradients (layer scale, conv layouts)."""
+        f, A = self.model.features, self._arena
+        from .._hip import call, ptr, stream
+        gname = lambda mod, leaf: A.g(self._pname[id(mod)] + "." + leaf)      # noqa: E731
+        stem = f[0][0]
+        # the stem temp is [C0, Kp] with zero-padded tail columns: relayout the first 16*Cin columns
+        kk = 16 * self.in_chans
+        src = tmp["stem.dw"][:, :kk].contiguous()
+        call("mmg_grad_relayout", ptr(src), ptr(gname(stem, "weight")), 0, self.dims[0], self.in_chans, 4, 4, kk, stream())
+        for si in range(4):
+            C = self.dims[si]
+            for bi, blk in enumerate(f[1 + 2 * si]):
+                key = f"{si}.{bi}"
+                call("mmg_layerscale_finalize", ptr(blk.block[5].weight.data), ptr(blk.block[5].bias.data),
+                     ptr(blk.layer_scale.data), ptr(tmp[key + ".dw2raw"]), ptr(tmp[key + ".db2raw"]),
+                     ptr(gname(blk.block[5], "weight")), ptr(gname(blk.block[5], "bias")),
+                     ptr(A.g(self._pname[id(blk)] + ".layer_scale")), C, 4 * C, stream())
+                call("mmg_grad_relayout", ptr(tmp[key + ".dw49"]), ptr(gname(blk.block[0], "weight")), 1, C, 1, 7, 7, C,
+                     stream())
+            if si < 3:
+                conv = f[2 + 2 * si][1]
+                call("mmg_grad_relayout", ptr(tmp[f"ds{si}.dw"]), ptr(gname(conv, "weight")), 0, self.dims[si + 1], C, 2, 2,
+                     4 * C, stream())
+
+    # ---- public -----------------------------------------------------------------------------------------------
+    def forward(self, images):
+        _hip.require_gpu(images)
+        self._materialize(images.device)
+        self._pname = {id(m): "features." + n for n, m in self.model.features.named_modules()}
+        needs_grad = torch.is_grad_enabled() and self._arena.any_trainable()
+        return _ConvNextFn.apply(self, images.float().contiguous(), self._anchor if needs_grad else None)
+
+
+class _ConvNextFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tower, images, anchor):
+        tower._refresh_working_copies()
+        save = anchor is not None
+        feats, saved = [], []
+        mb = tower.micro_batch
+        for i in range(0, images.shape[0], mb):
+            ft, sv = tower._forward_mb(images[i:i + mb], save)
+            feats.append(ft)
+            saved.append(sv)
+        ctx.tower, ctx.saved_mb = tower, saved if save else None
+        return torch.cat(feats, 0) if len(feats) > 1 else feats[0]
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        tower = ctx.tower
+        tower._arena.prepare_grads()
+        tmp = tower._alloc_tmp(dfeat.device)
+        dfeat = dfeat.float().contiguous()
+        i = 0
+        for sv in ctx.saved_mb:
+            n = sv["shape"][0]
+            tower._backward_mb(dfeat[i:i + n].contiguous(), sv, tmp)
+            sv.clear()
+            i += n
+        tower._finalize_grads(tmp)
+        ctx.saved_mb = None
+        return None, None, None

@@ -1,0 +1,142 @@
+"""`MMGCLIP(config)` — drop-in for mmgclip/networks/mmgclip_model.py:12-166 on the MI355X kernels.
+
+Same constructor, attributes (`config, device, text_encoder, image_projection_layer, text_projection_layer,
+logit_scale`, `image_encoder` when configured), methods (`count_parameters`, `encode_images`, `encode_text`,
+`forward(batch, **kwargs)`) and output-dict keys.  Differences are additive and config-gated:
+  * image encoders that take pixels (`ConvNextTinyEncoder`, `ConvNextBaseEncoder`); `ConvNextTiny` keeps the reference
+    behaviour (pre-extracted features pass through, no module built);
+  * `networks.learnable_logit_scale` (default false = the reference's behaviour on a GPU, where `.to(device)` turns
+    the Parameter into a constant tensor: SURVEY.md §0);
+  * `forward(..., materialize_logits=False)` skips the two [n,n] matrices for the fused loss path.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import head
+from ..utils.logger import logger
+from .bert import EosPool
+from .network_controller import getNetworkClass
+from .projection_controller import get_projection_head
+
+PIXEL_ENCODERS = ("ConvNextTinyEncoder", "ConvNextBaseEncoder")
+
+
+def _get(cfg, path, default=None):
+    cur = cfg
+    for k in path.split("."):
+        try:
+            cur = cur[k] if isinstance(cur, dict) else getattr(cur, k)
+        except (KeyError, AttributeError):
+            return default
+    return cur
+
+
+class MMGCLIP(nn.Module):
+    def __init__(self, config=None):
+        super().__init__()
+        assert config is not None, 'Error in initializing the model. Missing training config object.'
+        self.config = config
+        if not torch.cuda.is_available():
+            logger.warning("WARNING: No CUDA device is found. The MI355X kernels have no CPU fallback.")
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+        enc_name = self.config.networks.image_encoder.name
+        if enc_name == "ResNet50Encoder":
+            self.image_encoder = getNetworkClass(enc_name)(
+                pretrained=True, image_features_dimension=self.config.networks.image_encoder.image_features_dimension).to(self.device)
+        elif enc_name in PIXEL_ENCODERS:
+            ie = self.config.networks.image_encoder
+            self.image_encoder = getNetworkClass(enc_name)(
+                pretrained=_get(ie, "pretrained_path"), image_features_dimension=ie.image_features_dimension,
+                in_chans=_get(ie, "in_chans", 1), scale16=_get(ie, "scale16", True), micro_batch=_get(ie, "micro_batch", 16),
+                freeze=_get(ie, "freeze", False)).to(self.device)
+            logger.info(f"Using {self.image_encoder.__class__.__name__}")
+
+        te = self.config.networks.text_encoder
+        self.text_encoder = getNetworkClass(te.name)(
+            pretrained=self.config.tokenizer.config.tokenizer_name, freeze=_get(te, "freeze", True),
+            random_init=_get(te, "random_init", False)).to(self.device)
+
+        if self.config.projection.config.projection_name != "ZeroProjection":
+            head_cls = get_projection_head(self.config.projection.config.projection_name)
+            self.image_projection_layer = head_cls(
+                embedding_dim=self.config.networks.image_encoder.image_features_dimension,
+                projection_dim=self.config.projection.config.output_projection_dimension,
+                dropout=self.config.networks.dropout.config.dropout).to(self.device)
+            self.text_projection_layer = head_cls(
+                embedding_dim=self.text_encoder.model_output_dimension,
+                projection_dim=self.config.projection.config.output_projection_dimension,
+                dropout=self.config.networks.dropout.config.dropout).to(self.device)
+            logger.info(f"Embeddings are projected to {self.config.projection.config.output_projection_dimension} "
+                        f"features using {self.config.projection.config.projection_name}.")
+        else:
+            self.image_projection_layer = None
+            self.text_projection_layer = None
+
+        init = torch.ones([]) * np.log(1 / self.config.networks.logit_temperature)
+        if _get(self.config, "networks.learnable_logit_scale", False) or self.device.type == "cpu":
+            self.logit_scale = nn.Parameter(init.float().to(self.device))
+        else:
+            self.register_buffer("logit_scale", init.float().to(self.device), persistent=False)
+
+    def count_parameters(self, model):
+        """Logs a table of trainable parameters and returns their total count (mmgclip_model.py:54-74)."""
+        rows, total = [], 0
+        for name, parameter in model.named_parameters():
+            if not parameter.requires_grad:
+                continue
+            rows.append((name, parameter.numel()))
+            total += parameter.numel()
+        width = max([len(r[0]) for r in rows] + [7])
+        table = "\n".join([f"| {'Modules'.ljust(width)} | Parameters |"] + [f"| {n.ljust(width)} | {c:>10} |" for n, c in rows])
+        logger.info(f"\n{table}")
+        logger.info(f"Total Trainable Params: {total}")
+        return total
+
+    def encode_images(self, batch):
+        """[n,1,F,1,1] pre-extracted features -> [n,F] (mmgclip_model.py:76-93); pixel encoders take `batch['image']`
+        (or a 4-D `image_features`) and run the ConvNeXt tower."""
+        name = self.config.networks.image_encoder.name
+        if name in PIXEL_ENCODERS:
+            pix = batch["image"] if "image" in batch else batch["image_features"]
+            return self.image_encoder(pix.to(self.device))
+        flattened_embeddings = torch.flatten(batch['image_features'].to(self.device), 1)
+        if name == "ResNet50Encoder":
+            return self.image_encoder(flattened_embeddings)
+        return flattened_embeddings
+
+    def encode_text(self, batch, text_pooling='eos'):
+        """BERT last hidden state pooled at the [SEP] position = attention_mask.sum(-1) - 1 (mmgclip_model.py:95-115)."""
+        tokens = batch['text_tokens'].to(self.device) if hasattr(batch['text_tokens'], "to") else \
+            {k: v.to(self.device) for k, v in batch['text_tokens'].items()}
+        if isinstance(batch, dict):
+            batch['text_tokens'] = tokens                      # the reference's BatchEncoding.to() is in-place
+        hidden = self.text_encoder.hidden_states(tokens)       # bf16 [n*S, H]
+        if text_pooling == 'eos':
+            B, S = tokens['input_ids'].shape
+            return EosPool.apply(hidden, tokens['attention_mask'], B, S)
+        raise NotImplementedError(f"{text_pooling} method is not implemented...")
+
+    def forward(self, batch, **kwargs):
+        image_features = self.encode_images(batch)
+        text_features = self.encode_text(batch, text_pooling='eos')
+
+        image_embeddings = self.image_projection_layer(image_features) if self.image_projection_layer is not None else image_features
+        text_embeddings = self.text_projection_layer(text_features) if self.text_projection_layer is not None else text_features
+
+        image_embeddings = head.L2Normalize.apply(image_embeddings)        # :128
+        text_embeddings = head.L2Normalize.apply(text_embeddings)          # :129
+        logit_scale = self.logit_scale.exp()                               # :132
+
+        output = {"image_embeddings": image_embeddings, "text_embeddings": text_embeddings, "logit_scale": logit_scale}
+        if kwargs.get("materialize_logits", True):
+            li, lt = head.ScaledLogits.apply(image_embeddings, text_embeddings, logit_scale)   # :135-136
+            output["logits_per_image"], output["logits_per_text"] = li, lt
+
+        if self.config.loss.config.loss_name == "MMGCLIPLoss" and not kwargs.get('validation', False) == True:  # noqa: E712
+            batch['text_tokens'] = batch['image_impression_tokens']        # :160 (mutates the batch, like the reference)
+            text_features2 = self.encode_text(batch, text_pooling='eos')
+            text_embeddings2 = self.text_projection_layer(text_features2)
+            output['text_embeddings2'] = head.L2Normalize.apply(text_embeddings2)
+        return output

@@ -1,0 +1,82 @@
+"""CPU oracle for the two encoder towers — TEST INFRASTRUCTURE ONLY (see oracle/clip_oracle.py header).
+
+PARITY UNPINNED for this file: the arithmetic of both towers lives in third-party packages that are not in the
+reference tree — torchvision 0.14.1 `ConvNeXt` (inside a TorchScript archive the repo does not ship; torchvision is
+not installed here) and transformers 4.41.0 `BertModel` (5.15 installed) — and the reference holds no golden output
+for either.  The restatements below follow the published module definitions and the call order at
+the reference's call sites:
+    mmgclip/networks/encoder.py:40-55      ConvNextTiny.forward = model.features(x) -> model.avgpool(x)
+    mmgclip/networks/image_features.py:95-99   x*65535 ; (x - 32767.5)/32767.5
+    mmgclip/networks/encoder.py:146-156    BertEncoder.forward = model(**x)['last_hidden_state']
+    notebooks/clf_convnext_tiny_experimental.ipynb cell 3   (module tree)   notebooks/bert_experimental.ipynb:609-624 (config)
+tests/test_oracle_encoders.py cross-checks the BERT restatement against the installed transformers BertModel (eager
+attention, dropout 0) and the ConvNeXt geometry against the notebook's printed shapes ([1,1,1906,818] -> [1,768,59,25]).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def convnext_forward(sd, images, depths=(3, 3, 9, 3), scale16=True, prefix="features."):
+    """torchvision ConvNeXt `features` + `avgpool` from a state dict (fp32).  images [n,Cin,H,W]; returns [n,C,1,1]."""
+    x = images
+    if scale16:
+        x = 65535.0 * x
+        x = (x - 32767.5) / 32767.5
+    g = lambda k: sd[prefix + k]                                           # noqa: E731
+
+    def ln2d(x, k):      # LayerNorm2d: permute to NHWC, layer_norm over C, permute back
+        x = x.permute(0, 2, 3, 1)
+        x = F.layer_norm(x, (x.shape[-1],), g(k + ".weight"), g(k + ".bias"), 1e-6)
+        return x.permute(0, 3, 1, 2)
+
+    x = F.conv2d(x, g("0.0.weight"), g("0.0.bias"), stride=4)
+    x = ln2d(x, "0.1")
+    for si in range(4):
+        st = 1 + 2 * si
+        for bi in range(depths[si]):
+            k = f"{st}.{bi}."
+            C = x.shape[1]
+            y = F.conv2d(x, g(k + "block.0.weight"), g(k + "block.0.bias"), padding=3, groups=C)
+            y = y.permute(0, 2, 3, 1)
+            y = F.layer_norm(y, (C,), g(k + "block.2.weight"), g(k + "block.2.bias"), 1e-6)
+            y = F.linear(y, g(k + "block.3.weight"), g(k + "block.3.bias"))
+            y = F.gelu(y)
+            y = F.linear(y, g(k + "block.5.weight"), g(k + "block.5.bias"))
+            y = y.permute(0, 3, 1, 2)
+            x = x + g(k + "layer_scale") * y             # stochastic depth p = 0
+        if si < 3:
+            x = ln2d(x, f"{st + 1}.0")
+            x = F.conv2d(x, g(f"{st + 1}.1.weight"), g(f"{st + 1}.1.bias"), stride=2)
+    fmap = x
+    return F.adaptive_avg_pool2d(x, 1), fmap
+
+
+def bert_forward(sd, ids, attention_mask=None, token_type_ids=None, heads=12, eps=1e-12, prefix=""):
+    """HF BertModel.last_hidden_state (eval / dropout 0) from a state dict, fp32."""
+    g = lambda k: sd[prefix + k]                                           # noqa: E731
+    B, S = ids.shape
+    if token_type_ids is None:
+        token_type_ids = torch.zeros_like(ids)
+    x = g("embeddings.word_embeddings.weight")[ids] + g("embeddings.token_type_embeddings.weight")[token_type_ids] \
+        + g("embeddings.position_embeddings.weight")[:S][None]
+    H = x.shape[-1]
+    x = F.layer_norm(x, (H,), g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
+    add = None
+    if attention_mask is not None:
+        add = (1.0 - attention_mask.to(x.dtype))[:, None, None, :] * torch.finfo(x.dtype).min
+    i = 0
+    while prefix + f"encoder.layer.{i}.attention.self.query.weight" in sd:
+        p = f"encoder.layer.{i}."
+        lin = lambda t, k: F.linear(t, g(p + k + ".weight"), g(p + k + ".bias"))   # noqa: E731
+        split = lambda t: t.view(B, S, heads, H // heads).permute(0, 2, 1, 3)        # noqa: E731
+        q, k, v = split(lin(x, "attention.self.query")), split(lin(x, "attention.self.key")), split(lin(x, "attention.self.value"))
+        s = q @ k.transpose(-1, -2) / (H // heads) ** 0.5
+        if add is not None:
+            s = s + add
+        ctx = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, S, H)
+        a = F.layer_norm(lin(ctx, "attention.output.dense") + x, (H,), g(p + "attention.output.LayerNorm.weight"),
+                         g(p + "attention.output.LayerNorm.bias"), eps)
+        f = lin(F.gelu(lin(a, "intermediate.dense")), "output.dense")
+        x = F.layer_norm(f + a, (H,), g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"), eps)
+        i += 1
+    return x

@@ -1,0 +1,123 @@
+"""Encoder towers on the HIP kernels vs the fp32 CPU oracle (same state dict, same inputs).
+
+Tolerances: activations/weights are bf16 on the device (8 bits of mantissa), the oracle is fp32; features agree to
+~1e-2 relative, gradients are compared by cosine similarity (> 0.995) and relative L2 error (< 6e-2)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoders_oracle as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu().double().flatten(), b.detach().float().cpu().double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30)), float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _randomize(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("layer_scale"):
+                p.copy_(0.3 + 0.7 * torch.rand(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif "LayerNorm.weight" in n or (p.dim() == 1 and n.endswith("weight")):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif p.dim() >= 2 and "embeddings" not in n:
+                p.mul_(2.5)
+
+
+@pytest.mark.parametrize("size,n", [(64, 3), (96, 2)])
+def test_convnext_tower_forward_backward(dev, size, n):
+    from mmgclip.networks.encoder import ConvNextTinyEncoder
+    torch.manual_seed(0)
+    tower = ConvNextTinyEncoder(micro_batch=2)
+    _randomize(tower, 1)
+    sd = {k[len("model."):]: v.clone() for k, v in tower.state_dict().items()}
+    img = torch.rand(n, 1, size, size, generator=torch.Generator().manual_seed(2))
+    wgt = torch.randn(n, 768, generator=torch.Generator().manual_seed(3))
+    # oracle
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pooled, _ = E.convnext_forward(osd, img)
+    (pooled.flatten(1) * wgt).sum().backward()
+    # device
+    tower = tower.to(dev)
+    feat = tower(img.to(dev))
+    r, c = _rel(feat, pooled.flatten(1))
+    assert r < 2e-2 and c > 0.9995, (r, c)
+    (feat * wgt.to(dev)).sum().backward()
+    worst = {}
+    for name, p in tower.model.named_parameters():
+        r, c = _rel(p.grad, osd[name].grad)
+        worst[name] = (r, c)
+    bad = {k: v for k, v in worst.items() if not (v[1] > 0.995 and v[0] < 6e-2)}
+    assert not bad, f"{len(bad)} of {len(worst)} gradients off: {list(bad.items())[:8]}"
+
+
+def test_convnext_frozen_makes_no_graph(dev):
+    from mmgclip.networks.encoder import ConvNextTinyEncoder
+    tower = ConvNextTinyEncoder(freeze=True).to(dev)
+    out = tower(torch.rand(1, 1, 64, 64, device=dev))
+    assert not out.requires_grad and out.shape == (1, 768)
+
+
+def test_bert_tower_forward_backward(dev):
+    from mmgclip.networks.bert import BertConfigLite
+    from mmgclip.networks.encoder import BertEncoder
+    from mmgclip.dataset.synthetic import synthetic_tokens
+    torch.manual_seed(0)
+    cfg = BertConfigLite(vocab_size=3000, num_hidden_layers=3)
+    enc = BertEncoder(pretrained=None, random_init=True, freeze=False, config=cfg)
+    _randomize(enc, 4)
+    sd = {k[len("model."):]: v.clone() for k, v in enc.state_dict().items()}
+    tok = synthetic_tokens(4, 77, 3000, torch.Generator().manual_seed(5))
+    wgt = torch.randn(4 * 77, 768, generator=torch.Generator().manual_seed(6))
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = E.bert_forward(osd, tok["input_ids"], tok["attention_mask"], tok["token_type_ids"])
+    valid = tok["attention_mask"].reshape(-1, 1).float()          # padded query rows are don't-care downstream
+    (ref.reshape(-1, 768) * wgt * valid).sum().backward()
+    enc = enc.to(dev)
+    hid = enc.hidden_states({k: v.to(dev) for k, v in tok.items()})
+    r, c = _rel(hid.float() * valid.to(dev), ref.reshape(-1, 768) * valid)
+    assert r < 3e-2 and c > 0.999, (r, c)
+    (hid.float() * (wgt * valid).to(dev)).sum().backward()
+    bad = {}
+    for name, p in enc.model.named_parameters():
+        if name.startswith("pooler."):
+            continue
+        if name.endswith("attention.self.key.bias"):
+            # softmax is invariant to a shift of all keys: the exact gradient is 0, both sides only hold rounding noise
+            qb = enc.model.get_parameter(name.replace("key.bias", "query.bias")).grad
+            assert p.grad.abs().max() < 0.05 * qb.abs().max()
+            continue
+        r, c = _rel(p.grad, osd[name].grad)
+        if not (c > 0.99 and r < 0.12):
+            bad[name] = (r, c)
+    assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
+
+
+def test_bert_encoder_api_and_eos_pool(dev):
+    """BertEncoder.forward returns [B,S,H] like encoder.py:156; frozen by default (encoder.py:141-142)."""
+    from mmgclip.networks.bert import BertConfigLite, EosPool
+    from mmgclip.networks.encoder import BertEncoder
+    from mmgclip.dataset.synthetic import synthetic_tokens
+    from oracle import clip_oracle as O
+    enc = BertEncoder(pretrained="emilyalsentzer/Bio_ClinicalBERT", random_init=True,
+                      config=BertConfigLite(vocab_size=3000, num_hidden_layers=2))
+    assert all(not p.requires_grad for p in enc.parameters()) and enc.model_output_dimension == 768
+    sd = {k[len("model."):]: v.clone() for k, v in enc.state_dict().items()}
+    tok = synthetic_tokens(5, 40, 3000, torch.Generator().manual_seed(7))
+    enc = enc.to(dev)
+    dtok = {k: v.to(dev) for k, v in tok.items()}
+    out = enc(dtok)
+    assert out.shape == (5, 40, 768) and out.dtype == torch.float32
+    ref = E.bert_forward(sd, tok["input_ids"], tok["attention_mask"], tok["token_type_ids"])
+    pooled = EosPool.apply(enc.hidden_states(dtok), dtok["attention_mask"], 5, 40)
+    rp = O.eos_pool(ref, tok["attention_mask"])
+    r, c = _rel(pooled, rp)
+    assert r < 3e-2 and c > 0.999
+    with pytest.raises(OSError):
+        BertEncoder(pretrained="emilyalsentzer/Bio_ClinicalBERT")
