@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-text pairs/sec of the CLIP contrastive training step on MI355X (BASELINE.json).
+
+Workload at N GPUs (weak scaling, per-GPU work fixed): BASELINE config C2 per rank —
+`train_binary_class_clf` with ConvNeXt-T on 1024x1024 1-channel synthetic mammograms + BERT-base on 77-token synthetic
+prompts, LinearProjectionLayer 768->512 both towers, CLIPLoss (global batch through RCCL when N > 1), AdamW; bf16 towers,
+fp32 head; batch 256 per GPU.  A step = forward + backward + gradient all-reduce + optimizer step of every parameter of
+both towers (nothing frozen, nothing skipped).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     : the bf16 MFMA GEMM (gemm_nt_kernel) — algorithmic FLOPs of every launch / its HIP-event duration,
+                 measured in the timed region on the launch stream;
+  cpu_baseline : the CPU oracle (oracle/*, fp32 PyTorch restatement) on BASELINE config C1 (n=8, 224x224, S=77), timed
+                 on this host's cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch                                  # noqa: E402
+import torch.distributed as dist              # noqa: E402
+
+GFLOP_PER_PAIR = {  # fwd+bwd, 2 FLOP/MAC, train = 3 x forward
+    ("tiny", 1024, 77): 557.4 + 39.9, ("tiny", 224, 77): 26.7 + 39.9, ("base", 1024, 77): 1923.6 + 39.9,
+}
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def build(args, comm):
+    from mmgclip.config import compose
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    from mmgclip.optim import FusedAdamW
+    from mmgclip.utils.global_utils import seeding
+    net = "clip_convnexttiny_bert_pixels" if args.variant == "tiny" else "clip_convnextbase_bert_pixels"
+    cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf", [
+        f"networks={net}", f"tokenizer=bert_clinical_seqlen={args.seq_len}", "networks/dropout=dropout0",
+        f"networks.image_encoder.micro_batch={args.micro_batch}", f"networks.image_encoder.image_size={args.image_size}",
+        "optimizer.config.fused=true"])
+    seeding(cfg.base.seed)
+    model = MMGCLIP(cfg)
+    model.train()
+    criterion = create_loss(cfg.loss.config.loss_name)(comm=comm)
+    arenas = lambda: [model.image_encoder.arena, model.text_encoder.arena]      # noqa: E731
+    return cfg, model, criterion, arenas
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle training step (ConvNeXt-T + BERT-base + projection + CLIPLoss + AdamW, fp32) on config C1."""
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.networks.bert import BertConfigLite, _hf_layout
+    from mmgclip.networks.convnext import build_features
+    from oracle import clip_oracle as O
+    from oracle import encoders_oracle as E
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    feats, bert = build_features("tiny", 1), _hf_layout(BertConfigLite())
+    wi, wt = torch.nn.Linear(768, 512, bias=False), torch.nn.Linear(768, 512, bias=False)
+    ls = torch.tensor(2.6593)
+    params = list(feats.parameters()) + [p for n, p in bert.named_parameters() if not n.startswith("pooler.")] + \
+        list(wi.parameters()) + list(wt.parameters())
+    opt = torch.optim.AdamW(params, lr=5e-5, weight_decay=1e-4)
+    batch = synthetic_batch(8, S=77, image_size=224, seed=42)
+    csd = {"features." + k: v for k, v in feats.named_parameters()}
+    bsd = dict(bert.named_parameters())
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pooled, _ = E.convnext_forward(csd, batch["image"])
+        hid = E.bert_forward(bsd, batch["text_tokens"]["input_ids"], batch["text_tokens"]["attention_mask"],
+                             batch["text_tokens"]["token_type_ids"])
+        tf = O.eos_pool(hid, batch["text_tokens"]["attention_mask"])
+        out = O.forward_tail(O.linear_projection(pooled.flatten(1), wi.weight), O.linear_projection(tf, wt.weight), ls)
+        loss, _ = O.clip_loss(out["logits_per_image"], out["logits_per_text"])
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    step()                                   # warm-up
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < 3 or (time.time() < t_end and len(times) < 10):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(8 / med, 3), "unit": "image-text pairs/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 training step, config C1 (n=8, 224x224, S=77, ConvNeXt-T + BERT-base), "
+                      f"median of {len(times)} steps after 1 warm-up, {med * 1000:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="image-text pairs per GPU")
+    ap.add_argument("--image-size", type=int, default=1024)
+    ap.add_argument("--seq-len", type=int, default=77)
+    ap.add_argument("--micro-batch", type=int, default=16)
+    ap.add_argument("--variant", default="tiny", choices=["tiny", "base"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from mmgclip import distributed, linalg
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.optim import FusedAdamW
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    comm = distributed.init_from_env("nccl") if world > 1 else None
+    rank = comm.rank if comm else 0
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+
+    cfg, model, criterion, arenas = build(args, comm)
+    batch = synthetic_batch(args.batch, S=args.seq_len, image_size=args.image_size, seed=42 + rank)
+    batch["image"] = batch["image"].to(dev)
+    batch["text_tokens"] = batch["text_tokens"].to(dev)
+    torch.cuda.synchronize()
+
+    extra = [p for n, p in model.named_parameters() if not (n.startswith("image_encoder.") or n.startswith("text_encoder."))]
+    optimizer = None
+    sync = None
+
+    def step():
+        nonlocal optimizer, sync
+        if optimizer is not None:
+            optimizer.zero_grad(set_to_none=True)
+        outputs = model(batch, materialize_logits=False)
+        loss, _ = criterion(**outputs)
+        if sync is None:                      # arenas exist after the first forward
+            sync = distributed.GradSync(comm, arenas(), extra)
+            if comm is not None:
+                model.image_encoder.post_backward_hook = sync.reduce_arena_async
+                model.text_encoder.post_backward_hook = sync.reduce_arena_async
+        loss.backward()
+        sync.finish()
+        if optimizer is None:
+            optimizer = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.optimizer.config.learning_rate,
+                                   weight_decay=cfg.optimizer.config.weight_decay, arenas=arenas())
+        optimizer.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if comm is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(step().item())
+    if not args.no_roofline:
+        linalg.PROFILE.enable()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    linalg.PROFILE.disable()
+    losses.append(loss.item())
+    if comm is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    ms_per_step = elapsed / args.steps * 1000.0
+    pairs = args.batch * world * args.steps
+    value = pairs / elapsed
+    gflop = GFLOP_PER_PAIR.get((args.variant, args.image_size, args.seq_len))
+    out = {
+        "metric": "image-text pairs/sec (global batch)", "value": round(value, 2), "unit": "image-text pairs/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"C2: train_binary_class_clf, ConvNeXt-{args.variant} {args.image_size}x{args.image_size}x1 + BERT-base "
+                               f"S={args.seq_len}, LinearProjection 768->512, CLIPLoss, AdamW, all parameters trained",
+                   "global_batch": args.batch * world, "per_gpu_batch": args.batch, "micro_batch": args.micro_batch,
+                   "parallelism": f"dp{world}", "loss_scope": "global (all-gather)" if world > 1 else "local",
+                   "algorithmic_gflop_per_pair": gflop,
+                   "model_tflops_per_gpu": round(value * gflop / 1000.0 / world, 1) if gflop else None,
+                   "mfma_utilisation_model_flops": round(value * gflop / 1000.0 / world / MFMA_BF16_PEAK_TFLOPS, 4) if gflop else None,
+                   "final_loss": round(losses[-1], 5)},
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            out["roofline"] = linalg.PROFILE.summary(MFMA_BF16_PEAK_TFLOPS)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

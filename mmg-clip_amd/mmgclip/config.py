@@ -52,13 +52,27 @@ def _set_path(cfg, dotted, value):
     cur[parts[-1]] = value
 
 
+_SCI = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)[eE][+-]?\d+$")
+
+
+def _fix_scalars(node):
+    """PyYAML (YAML 1.1) reads `5e-5` as a string; OmegaConf reads it as a float — follow OmegaConf."""
+    if isinstance(node, dict):
+        return {k: _fix_scalars(v) for k, v in node.items()}
+    if isinstance(node, list):
+        return [_fix_scalars(v) for v in node]
+    if isinstance(node, str) and _SCI.match(node):
+        return float(node)
+    return node
+
+
 def _load_yaml(path):
     with open(path) as fh:
-        return yaml.safe_load(fh) or {}
+        return _fix_scalars(yaml.safe_load(fh) or {})
 
 
 def _parse_value(text):
-    return yaml.safe_load(text)
+    return _fix_scalars(yaml.safe_load(text))
 
 
 def compose(config_dir, config_name, overrides=()):

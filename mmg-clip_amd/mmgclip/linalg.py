@@ -42,3 +42,50 @@ def colsum_acc(a, out):
     M, N = a.shape
     call("mmg_colsum_bf16", ptr(a), _ld(a), M, N, ptr(out), stream())
     return out
+
+
+class _GemmProfile:
+    """HIP-event timing of every gemm_nt launch (bench.py's roofline leg).  Events are recorded on the stream the kernel
+    is launched on (torch's current stream), so the durations are the kernel's own; flops are the algorithmic 2*M*N*K."""
+
+    def __init__(self):
+        self.on = False
+        self.records = []        # (start, end, flops, bytes)
+
+    def enable(self):
+        self.on, self.records = True, []
+
+    def disable(self):
+        self.on = False
+
+    def summary(self, peak_tflops):
+        if not self.records:
+            return None
+        torch.cuda.synchronize()
+        t_ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        flops = sum(f for _, _, f, _ in self.records)
+        byts = sum(b for _, _, _, b in self.records)
+        n = len(self.records)
+        ach = flops / (t_ms * 1e-3) / 1e12
+        return {"kernel": "gemm_nt_kernel (bf16 MFMA, all shapes of the step)", "bound": "mfma", "achieved": round(ach, 1),
+                "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4), "traffic": None,
+                "launches": n, "avg_launch_us": round(t_ms * 1000.0 / n, 1), "total_ms": round(t_ms, 2),
+                "algorithmic_gbytes_per_s": round(byts / (t_ms * 1e-3) / 1e9, 1)}
+
+
+PROFILE = _GemmProfile()
+_gemm_nt_raw = gemm_nt
+
+
+def gemm_nt(a, b, out=None, **kw):       # noqa: F811  (profiling shim around the launch)
+    if not PROFILE.on:
+        return _gemm_nt_raw(a, b, out=out, **kw)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = _gemm_nt_raw(a, b, out=out, **kw)
+    e.record()
+    M, K = a.shape
+    N = b.shape[0]
+    byts = 2 * (M * K + N * K) + r.element_size() * M * N
+    PROFILE.records.append((s, e, 2.0 * M * N * K, byts))
+    return r

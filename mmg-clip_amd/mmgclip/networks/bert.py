@@ -84,6 +84,7 @@ class BertTower(nn.Module):
         self._wc = None
         self._wc_version = None
         self._anchor = None
+        self.post_backward_hook = None      # called with the arena once this tower's gradients are complete
 
     # ---- parameter plumbing: arena order puts q,k,v (weights, then biases) of a layer next to each other -----
     def _ordered_named_parameters(self):
@@ -247,6 +248,8 @@ class _BertFn(torch.autograd.Function):
             tower._backward_mb(dh[row:row + B * S], sv)
             row += B * S
         ctx.saved_mb = None
+        if tower.post_backward_hook is not None:
+            tower.post_backward_hook(tower._arena)
         return None, None, None, None, None
 
 

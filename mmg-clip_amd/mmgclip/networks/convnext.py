@@ -91,6 +91,7 @@ class ConvNextTower(nn.Module):
         self._wc = None
         self._wc_version = None
         self._anchor = None
+        self.post_backward_hook = None      # called with the arena once this tower's gradients are complete
 
     # ---- parameter plumbing ------------------------------------------------------------------------------
     def _materialize(self, device):
@@ -288,4 +289,6 @@ class _ConvNextFn(torch.autograd.Function):
             i += n
         tower._finalize_grads(tmp)
         ctx.saved_mb = None
+        if tower.post_backward_hook is not None:
+            tower.post_backward_hook(tower._arena)
         return None, None, None

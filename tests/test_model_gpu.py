@@ -1,0 +1,122 @@
+"""End-to-end MMGCLIP on the MI355X kernels vs the CPU oracle with the same weights and batch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle as O
+from oracle import encoders_oracle as E
+
+pytestmark = pytest.mark.gpu
+CFG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmg-clip_amd", "configs")
+
+
+def _cfg(*over):
+    from mmgclip.config import compose
+    return compose(CFG_DIR, "train_binary_class_clf", list(over))
+
+
+def _small_bert(monkeypatch, layers=2, vocab=3000):
+    """Shrink the text tower for the CPU oracle's sake (architecture per layer unchanged)."""
+    from mmgclip.networks import bert
+    orig = bert.BertConfigLite.__init__
+
+    def small(self, **kw):
+        kw.setdefault("num_hidden_layers", layers)
+        kw.setdefault("vocab_size", vocab)
+        orig(self, **kw)
+    monkeypatch.setattr(bert.BertConfigLite, "__init__", small)
+
+
+def _oracle_outputs(model, batch, pixels):
+    sd = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
+    tok = {k: v.cpu() for k, v in batch["text_tokens"].items()}
+    hid = E.bert_forward({k[len("text_encoder.model."):]: v for k, v in sd.items() if k.startswith("text_encoder.model.")},
+                         tok["input_ids"], tok["attention_mask"], tok["token_type_ids"])
+    tf = O.eos_pool(hid, tok["attention_mask"])
+    if pixels:
+        csd = {k[len("image_encoder.model."):]: v for k, v in sd.items() if k.startswith("image_encoder.model.")}
+        imf = E.convnext_forward(csd, batch["image"].cpu())[0].flatten(1)
+    else:
+        imf = batch["image_features"].cpu().flatten(1)
+    ls = torch.tensor(float(np.log(1 / 0.07)))
+    return O.forward_tail(O.linear_projection(imf, sd["image_projection_layer.layer.weight"]),
+                          O.linear_projection(tf, sd["text_projection_layer.layer.weight"]), ls)
+
+
+def test_reference_faithful_mode(dev, monkeypatch):
+    """Reference defaults: pre-extracted ConvNeXt features pass through, frozen BERT, 2 trainable 768->512 linears."""
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    _small_bert(monkeypatch)
+    torch.manual_seed(0)
+    cfg = _cfg("networks.text_encoder.random_init=true", "tokenizer=bert_clinical_seqlen=77")
+    model = MMGCLIP(cfg)
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert trainable == ["image_projection_layer.layer.weight", "text_projection_layer.layer.weight"]
+    assert "logit_scale" not in model.state_dict()            # reference-on-GPU behaviour
+    batch = synthetic_batch(32, S=77, vocab_size=3000, seed=3)
+    ref = _oracle_outputs(model, batch, pixels=False)
+    out = model(batch)
+    assert set(out) == {"image_embeddings", "text_embeddings", "logit_scale", "logits_per_image", "logits_per_text"}
+    np.testing.assert_allclose(out["logits_per_image"].detach().cpu().numpy(), ref["logits_per_image"].numpy(), atol=0.15)
+    loss, labels = create_loss("CLIPLoss")()(**out)
+    ref_loss, _ = O.clip_loss(ref["logits_per_image"], ref["logits_per_text"])
+    assert abs(loss.item() - ref_loss.item()) < 1e-2 * abs(ref_loss.item())      # bf16 towers vs fp32 oracle
+    assert labels.tolist() == list(range(32))
+    loss.backward()
+    assert model.image_projection_layer.layer.weight.grad is not None
+    assert batch["text_tokens"]["input_ids"].is_cuda           # in-place .to(device) like BatchEncoding
+
+
+def test_pixel_mode_training_step_matches_oracle_and_learns(dev, monkeypatch):
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    from mmgclip.optim import FusedAdamW
+    _small_bert(monkeypatch)
+    torch.manual_seed(0)
+    cfg = _cfg("networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_seqlen=77", "networks/dropout=dropout0",
+               "networks.image_encoder.micro_batch=4", "networks.image_encoder.image_size=64")
+    model = MMGCLIP(cfg).train()
+    with torch.no_grad():                                      # make the blocks matter (layer scale is 1e-6 at init)
+        for n, p in model.named_parameters():
+            if n.endswith("layer_scale"):
+                p.fill_(0.5)
+    batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=4)
+    ref = _oracle_outputs(model, batch, pixels=True)
+    ref_loss, _ = O.clip_loss(ref["logits_per_image"], ref["logits_per_text"])
+    crit = create_loss("CLIPLoss")()
+    out = model(batch, materialize_logits=False)
+    assert "logits_per_image" not in out
+    loss, _ = crit(**out)
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    loss.backward()
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-4,
+                     arenas=[model.image_encoder.arena, model.text_encoder.arena])
+    first = loss.item()
+    for _ in range(12):
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        loss, _ = crit(**model(batch, materialize_logits=False))
+        loss.backward()
+    assert loss.item() < 0.6 * first, (first, loss.item())     # the whole step (both towers) optimises the loss
+
+
+def test_mmgclip_and_averaged_losses(dev, golden_dir):
+    from mmgclip.loss.loss_controller import create_loss
+    g = np.load(os.path.join(golden_dir, "g2_head_n32.npz"))
+    t = lambda k: torch.from_numpy(g[k]).to(dev)                 # noqa: E731
+    loss, labels = create_loss("MMGCLIPLoss")()(image_embeddings=t("image_embeddings"), text_embeddings=t("text_embeddings"),
+                                                text_embeddings2=t("text_embeddings2"), logit_scale=t("scale"))
+    assert abs(loss.item() - float(g["mmg_loss"])) < 5e-6 * abs(float(g["mmg_loss"]))
+    a = np.load(os.path.join(golden_dir, "g3_averaged.npz"))
+    ref = O.forward_tail(torch.from_numpy(a["img"]), torch.from_numpy(a["txt"]), torch.from_numpy(a["logit_scale_param"]))
+    dev_out = {k: v.to(dev) for k, v in ref.items()}
+    loss, labels = create_loss("AveragedMedicalCLIPLoss")()(**dev_out)
+    assert labels.cpu().tolist() == a["labels"].tolist()
+    assert abs(loss.item() - float(a["loss"])) < 1e-5 * abs(float(a["loss"]))
+    with pytest.raises(ValueError):
+        create_loss("NoSuchLoss")
