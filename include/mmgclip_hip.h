@@ -96,9 +96,10 @@ int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, in
                      int ldai, void* aux_out, int ldao, int epi, int out_f32, float alpha, mmg_stream_t stream);
 
 /* Weight gradient: C[N1,N2] += alpha * A[M,N1]^T B[M,N2]  (A,B bf16; C fp32, accumulated with atomics, so the
- * caller zeroes C once per optimisation step).  Autograd of the linears above w.r.t. their weights. */
+ * caller zeroes C once per optimisation step).  colsum_a (nullable, fp32 [N1]) += alpha * column sums of A: the bias
+ * gradient of the same linear, fused as one extra MFMA per fragment.  Autograd of the linears above. */
 int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
-                     float alpha, mmg_stream_t stream);
+                     float alpha, float* colsum_a, mmg_stream_t stream);
 
 /* Bias gradient: out[n] += sum_m A[m,n]  (A bf16 [M,N]). */
 int mmg_colsum_bf16(const void* A, int lda, int M, int N, float* out, mmg_stream_t stream);

@@ -102,6 +102,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmNT g
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // epilogue geometry: each thread owns 8 consecutive columns of a row, PASSES rows per thread.  Its per-column
+    // vectors are fetched now so their latency hides under the main loop.
+    constexpr int TPR = BN / 8;                       // threads per row
+    constexpr int RPP = GEMM_THREADS / TPR;           // rows per pass
+    constexpr int PASSES = (BM + RPP - 1) / RPP;
+    const int tr = tid / TPR, tc = (tid % TPR) * 8;
+    const int gc = n0 + tc;
+    const bool col_ok = (tr < RPP) && (gc < g.N);
+    float bias[8], cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bias[e] = (col_ok && g.bias) ? g.bias[gc + e] : 0.f;
+        cs[e] = (col_ok && g.colscale) ? g.colscale[gc + e] : 1.f;
+    }
+
     const int nk = g.K / BK;
     stage_rows<BM, BK>(g.A, g.lda, m0, g.M, 0, NT_AS(0), tid);
     stage_rows<BN, BK>(g.B, g.ldb, n0, g.N, 0, NT_BS(0), tid);
@@ -129,6 +144,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmNT g
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
+
+    // issue EVERY global read of the epilogue (residual / saved pre-activation rows of all passes) before the
+    // accumulators go through LDS: with two workgroups per CU nothing else would hide their latency pass by pass.
+    uint4 res_v[PASSES], aux_v[PASSES];
+    const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DRELU);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int gr = m0 + tr + p * RPP;
+        const bool ok = col_ok && (tr + p * RPP < BM) && (gr < g.M);
+        res_v[p] = make_uint4(0, 0, 0, 0);
+        aux_v[p] = make_uint4(0, 0, 0, 0);
+        if (ok && g.residual) res_v[p] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
+        if (ok && want_aux) aux_v[p] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
+    }
     __syncthreads();   // all fragment reads done before the staging buffers become the C tile
 
     // accumulators -> LDS (row = m, 4 consecutive n per lane)
@@ -143,68 +172,56 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmNT g
         }
     __syncthreads();
 
-    // coalesced epilogue: each thread owns 8 consecutive columns of a row
-    constexpr int TPR = BN / 8;                       // threads per row
-    constexpr int RPP = GEMM_THREADS / TPR;           // rows per pass
-    const int tr = tid / TPR, tc = (tid % TPR) * 8;
-    const int gc = n0 + tc;
-    if (tr < RPP && gc < g.N) {
-        float bias[8], cs[8];
+    if (!col_ok) return;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            bias[e] = g.bias ? g.bias[gc + e] : 0.f;
-            cs[e] = g.colscale ? g.colscale[gc + e] : 1.f;
-        }
-        for (int r = tr; r < BM; r += RPP) {
-            const int gr = m0 + r;
-            if (gr >= g.M) break;
-            float v[8];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDCS + tc);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDCS + tc + 4);
+    for (int p = 0; p < PASSES; ++p) {
+        const int r = tr + p * RPP;
+        const int gr = m0 + r;
+        if (r >= BM || gr >= g.M) continue;
+        float v[8];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDCS + tc);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDCS + tc + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bias[e];
-            if (g.epi == EPI_GELU || g.epi == EPI_RELU) {
-                if (g.aux_out) {
-                    uint4 o;
-                    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-                    *reinterpret_cast<uint4*>(g.aux_out + (size_t)gr * g.ldao + gc) = o;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
-            } else if (g.epi == EPI_DGELU || g.epi == EPI_DRELU) {
-                const uint4 h = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
-                const unsigned hw[4] = {h.x, h.y, h.z, h.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
-                    if (g.epi == EPI_DGELU) {
-                        v[2 * e] *= gelu_grad_f(h0);
-                        v[2 * e + 1] *= gelu_grad_f(h1);
-                    } else {
-                        v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;
-                        v[2 * e + 1] = h1 > 0.f ? v[2 * e + 1] : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= cs[e];
-            if (g.residual) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
-                const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
-            }
-            if (g.out_f32) {
-                float* dst = reinterpret_cast<float*>(g.C) + (size_t)gr * g.ldc + gc;
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], g.alpha, bias[e]);
+        if (g.epi == EPI_GELU || g.epi == EPI_RELU) {
+            if (g.aux_out) {
                 uint4 o;
                 o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (size_t)gr * g.ldc + gc) = o;
+                *reinterpret_cast<uint4*>(g.aux_out + (size_t)gr * g.ldao + gc) = o;
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
+        } else if (want_aux) {
+            const unsigned hw[4] = {aux_v[p].x, aux_v[p].y, aux_v[p].z, aux_v[p].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
+                if (g.epi == EPI_DGELU) {
+                    v[2 * e] *= gelu_grad_f(h0);
+                    v[2 * e + 1] *= gelu_grad_f(h1);
+                } else {
+                    v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;
+                    v[2 * e + 1] = h1 > 0.f ? v[2 * e + 1] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= cs[e];
+        if (g.residual) {
+            const unsigned rw[4] = {res_v[p].x, res_v[p].y, res_v[p].z, res_v[p].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
+        }
+        if (g.out_f32) {
+            float* dst = reinterpret_cast<float*>(g.C) + (size_t)gr * g.ldc + gc;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            uint4 o;
+            o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (size_t)gr * g.ldc + gc) = o;
         }
     }
 }
@@ -257,6 +274,7 @@ struct GemmTN {
     const bf16_t* A; const bf16_t* B;
     int M, N1, N2, lda, ldb;
     float* C; int ldc;
+    float* colsum_a;          // [N1] += column sums of A (bias gradient of the same linear), nullable
     int tiles1, tiles2, rows_per_chunk;
     float alpha;
 };
@@ -319,6 +337,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const GemmTN g
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient: one extra MFMA per A fragment against an all-ones operand gives the column sums of A in every
+    // accumulator row; only the workgroups of the first N2 tile (and their w2 == 0 waves) do it.
+    const bool do_colsum = (g.colsum_a != nullptr) && (t2 == 0) && (w2 == 0);
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const short one_bf = (short)0x3F80;
+    const bf16x8 ones = {one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
 
     const int nk = (m_end - m_begin + TN_BK - 1) / TN_BK;
     stage_tn(g.A, g.lda, m_begin, g.M, c1, g.N1, TN_AS(0), tid);
@@ -354,6 +380,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const GemmTN g
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+            }
+        }
+    }
+    if (do_colsum && lg == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n1 = c1 + w1 * 64 + i * 16 + li;
+            if (n1 < g.N1) atomicAdd(g.colsum_a + n1, accb[i][0] * g.alpha);
         }
     }
     __syncthreads();
@@ -377,7 +414,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const GemmTN g
 }
 
 MMG_API int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
-                             float alpha, hipStream_t stream) {
+                             float alpha, float* colsum_a, hipStream_t stream) {
     MMG_CHECK_ARG(A && B && C, "mmg_gemm_tn_bf16: null operand");
     MMG_CHECK_ARG(M > 0 && N1 >= 8 && N2 >= 8, "mmg_gemm_tn_bf16: M=%d N1=%d N2=%d", M, N1, N2);
     MMG_CHECK_ARG(N1 % 8 == 0 && N2 % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= N1 && ldb >= N2 && ldc >= N2,
@@ -385,7 +422,7 @@ MMG_API int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, flo
                   lda, ldb, ldc);
     GemmTN g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N1 = N1; g.N2 = N2; g.lda = lda; g.ldb = ldb;
-    g.C = C; g.ldc = ldc; g.alpha = alpha;
+    g.C = C; g.ldc = ldc; g.alpha = alpha; g.colsum_a = colsum_a;
     g.tiles1 = cdiv(N1, TN_T);
     g.tiles2 = cdiv(N2, TN_T);
     const int tiles = g.tiles1 * g.tiles2;

@@ -27,13 +27,14 @@ def gemm_nt(a, b, out=None, bias=None, colscale=None, residual=None, aux_in=None
     return out
 
 
-def gemm_tn_acc(a, b, out, alpha=1.0):
-    """out[N1,N2] (fp32) += alpha * a[M,N1].T @ b[M,N2]."""
+def gemm_tn_acc(a, b, out, alpha=1.0, colsum=None):
+    """out[N1,N2] (fp32) += alpha * a[M,N1].T @ b[M,N2];  colsum[N1] (fp32, optional) += alpha * a.sum(0)."""
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and out.dtype == torch.float32
     M, N1 = a.shape
     N2 = b.shape[1]
     assert b.shape[0] == M and out.shape == (N1, N2)
-    call("mmg_gemm_tn_bf16", ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out), M, N1, N2, float(alpha), stream())
+    call("mmg_gemm_tn_bf16", ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out), M, N1, N2, float(alpha), ptr(colsum),
+         stream())
     return out
 
 

@@ -176,26 +176,22 @@ class BertTower(nn.Module):
             df = K.layernorm_bwd(dx, f, m2, r2, lyr.output.LayerNorm.weight.data, A.g(p + "output.LayerNorm.weight"),
                                  A.g(p + "output.LayerNorm.bias"))
             g = K.gelu(hpre)
-            L.gemm_tn_acc(df, g, A.g(p + "output.dense.weight"))
-            L.colsum_acc(df, A.g(p + "output.dense.bias"))
+            L.gemm_tn_acc(df, g, A.g(p + "output.dense.weight"), colsum=A.g(p + "output.dense.bias"))
             del g
             dh = L.gemm_nt(df, wc[f"{i}.wft"], epi=L.EPI_DGELU, aux_in=hpre)
-            L.gemm_tn_acc(dh, x1, A.g(p + "intermediate.dense.weight"))
-            L.colsum_acc(dh, A.g(p + "intermediate.dense.bias"))
+            L.gemm_tn_acc(dh, x1, A.g(p + "intermediate.dense.weight"), colsum=A.g(p + "intermediate.dense.bias"))
             dx1 = L.gemm_nt(dh, wc[f"{i}.wit"], residual=df)          # + residual path of the FFN block
             del dh, df
             da = K.layernorm_bwd(dx1, a, m1, r1, lyr.attention.output.LayerNorm.weight.data,
                                  A.g(p + "attention.output.LayerNorm.weight"), A.g(p + "attention.output.LayerNorm.bias"))
             del dx1
-            L.gemm_tn_acc(da, ctx, A.g(p + "attention.output.dense.weight"))
-            L.colsum_acc(da, A.g(p + "attention.output.dense.bias"))
+            L.gemm_tn_acc(da, ctx, A.g(p + "attention.output.dense.weight"), colsum=A.g(p + "attention.output.dense.bias"))
             dctx = L.gemm_nt(da, wc[f"{i}.wot"])
             dqkv = K.attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads)
             del dctx
             gw = A.gspan(p + "attention.self.query.weight", p + "attention.self.value.weight")[:3 * H * H].view(3 * H, H)
             gb = A.gspan(p + "attention.self.query.bias", p + "attention.self.value.bias")[:3 * H]
-            L.gemm_tn_acc(dqkv, x, gw)
-            L.colsum_acc(dqkv, gb)
+            L.gemm_tn_acc(dqkv, x, gw, colsum=gb)
             dx = L.gemm_nt(dqkv, wc[f"{i}.wqkvt"], residual=da)       # + residual path of the attention block
             del dqkv, da
             saved["layers"][i] = None

@@ -182,8 +182,7 @@ class ConvNextTower(nn.Module):
             if si < 3:
                 x, mean, rstd, ld = saved[f"ds{si}"]
                 conv, lnm = f[2 + 2 * si][1], f[2 + 2 * si][0]
-                L.gemm_tn_acc(dx, ld, tmp[f"ds{si}.dw"])
-                L.colsum_acc(dx, gname(conv, "bias"))
+                L.gemm_tn_acc(dx, ld, tmp[f"ds{si}.dw"], colsum=gname(conv, "bias"))
                 dld = L.gemm_nt(dx, wc[f"ds{si}.wt"])
                 h, w_ = h * 2, w_ * 2
                 dx = K.layernorm_bwd(dld, x, mean, rstd, lnm.weight.data, gname(lnm, "weight"), gname(lnm, "bias"),
@@ -194,13 +193,11 @@ class ConvNextTower(nn.Module):
                 key = f"{si}.{bi}"
                 x, d, mean, rstd, hpre = saved[key]
                 g = K.gelu(hpre)
-                L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"])
-                L.colsum_acc(dx, tmp[key + ".db2raw"])
+                L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
                 del g
                 dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre)
                 ln, _, _ = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=False)
-                L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"))
-                L.colsum_acc(dh, gname(blk.block[3], "bias"))
+                L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
                 del ln
                 dln = L.gemm_nt(dh, wc[key + ".w1t"])
                 del dh
@@ -212,8 +209,7 @@ class ConvNextTower(nn.Module):
                 del dd
         p0, s0, mean, rstd = saved["stem"]
         ds0 = K.layernorm_bwd(dx, s0, mean, rstd, f[0][1].weight.data, gname(f[0][1], "weight"), gname(f[0][1], "bias"))
-        L.gemm_tn_acc(ds0, p0, tmp["stem.dw"])
-        L.colsum_acc(ds0, gname(f[0][0], "bias"))
+        L.gemm_tn_acc(ds0, p0, tmp["stem.dw"], colsum=gname(f[0][0], "bias"))
 
     def _alloc_tmp(self, device):
         z = lambda *s: torch.zeros(*s, device=device, dtype=torch.float32)   # noqa: E731

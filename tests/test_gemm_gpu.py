@@ -79,9 +79,11 @@ def test_tn(dev, M, N1, N2):
     from mmgclip import linalg
     a, b = _rand((M, N1), dev, 1.0, 7), _rand((M, N2), dev, 1.0, 8)
     out = torch.ones(N1, N2, device=dev)           # accumulate semantics
-    linalg.gemm_tn_acc(a, b, out)
+    cs = torch.full((N1,), 2.0, device=dev)        # fused bias gradient (column sums of a), also accumulated
+    linalg.gemm_tn_acc(a, b, out, colsum=cs)
     ref = 1.0 + (a.double().t() @ b.double()).float()
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
+    np.testing.assert_allclose(cs.cpu().numpy(), 2.0 + a.double().sum(0).float().cpu().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
 
 
 def test_colsum(dev):
