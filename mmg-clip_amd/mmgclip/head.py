@@ -119,21 +119,51 @@ def cross_entropy(logits, labels=None, weight=1.0):
     return CrossEntropyRows.apply(logits, labels, weight)
 
 
+class _HipHeadBackend:
+    """The product arithmetic of the fused loss: three entry points of libmmgclip_hip.so.
+
+    (tests/test_distributed_cpu.py swaps in an oracle-backed object with the same three methods to exercise the
+    collective choreography below on CPU/gloo; the product path never does.)"""
+
+    @staticmethod
+    def rows_forward(x_loc, y_all, scale, diag_off):
+        lse, pos, _ = rows_forward(x_loc, y_all, scale, diag_off)
+        return lse, pos
+
+    @staticmethod
+    def loss_sum(lse_i, pos_i, lse_t, pos_t, coef):
+        loss = torch.zeros(1, device=lse_i.device, dtype=torch.float32)
+        call("mmg_clip_loss_reduce", ptr(lse_i), ptr(pos_i), ptr(lse_t), ptr(pos_t), lse_i.shape[0], coef, ptr(loss), stream())
+        return loss
+
+    @staticmethod
+    def rows_backward(x_loc, y_all, scale, lse_row, lse_col, gout, coef, diag_off, want_dscale):
+        n_loc, D = x_loc.shape
+        dx = torch.empty_like(x_loc)
+        dscale = torch.zeros(1, device=x_loc.device, dtype=torch.float32) if want_dscale else None
+        call("mmg_clip_rows_bwd_fused", ptr(x_loc), ptr(y_all), ptr(scale), ptr(lse_row), ptr(lse_col), ptr(gout), coef,
+             n_loc, y_all.shape[0], D, diag_off, ptr(dx), ptr(dscale), stream())
+        return dx, dscale
+
+
 class FusedClipLoss(torch.autograd.Function):
     """CLIPLoss over (already L2-normalised) embeddings without materialising logits.
 
     loss = 1/(2N) [ sum_i (lse_i(A) - A_ii) + sum_j (lse_j(A^T) - A_jj) ],  A = s I T^T   (losses.py:36-44)
 
-    With a process group the columns are the all-gathered embeddings of every rank: exchange 1
+    With a communicator the columns are the all-gathered embeddings of every rank: exchange 1
     gathers the normalised embeddings, exchange 2 the two log-sum-exp vectors; gradients w.r.t. the local
-    embeddings are then complete locally (no reduce-scatter).  `group=None` is the reference's local-batch loss.
+    embeddings are then complete locally (no reduce-scatter).  `comm=None` is the reference's local-batch loss.
     The returned loss is the GLOBAL mean (identical on every rank); gradients are d(global loss)/d(local rows),
-    so parameter gradients must be SUMMED across ranks (mmgclip/distributed.py does that).
+    so parameter gradients must be SUMMED across ranks (mmgclip/distributed.py does that).  d loss / d scale is the
+    LOCAL rows' share; summed over ranks it is the full derivative.
     """
 
     @staticmethod
-    def forward(ctx, img, txt, scale, comm):
-        _hip.require_gpu(img, txt, scale)
+    def forward(ctx, img, txt, scale, comm, backend):
+        be = backend or _HipHeadBackend
+        if backend is None:
+            _hip.require_gpu(img, txt, scale)
         img, txt = _f32c(img), _f32c(txt)
         scale = _f32c(scale.reshape(1))
         n_loc, D = img.shape
@@ -142,37 +172,28 @@ class FusedClipLoss(torch.autograd.Function):
         else:
             img_all, txt_all = comm.all_gather_rows(img), comm.all_gather_rows(txt)
             off, N = comm.rank * n_loc, n_loc * comm.world_size
-        lse_i, pos_i, _ = rows_forward(img, txt_all, scale, off)
-        lse_t, pos_t, _ = rows_forward(txt, img_all, scale, off)
-        loss = torch.zeros(1, device=img.device, dtype=torch.float32)
-        call("mmg_clip_loss_reduce", ptr(lse_i), ptr(pos_i), ptr(lse_t), ptr(pos_t), n_loc, 1.0 / (2.0 * N),
-             ptr(loss), stream())
+        lse_i, pos_i = be.rows_forward(img, txt_all, scale, off)
+        lse_t, pos_t = be.rows_forward(txt, img_all, scale, off)
+        loss = be.loss_sum(lse_i, pos_i, lse_t, pos_t, 1.0 / (2.0 * N))
         if comm is not None and comm.world_size > 1:
             lse_i_all, lse_t_all = comm.all_gather_rows(lse_i), comm.all_gather_rows(lse_t)
             loss = comm.all_reduce_sum(loss)
         else:
             lse_i_all, lse_t_all = lse_i, lse_t
         ctx.save_for_backward(img, txt, scale, img_all, txt_all, lse_i, lse_t, lse_i_all, lse_t_all)
-        ctx.off, ctx.N = off, N
+        ctx.off, ctx.N, ctx.be = off, N, be
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
         img, txt, scale, img_all, txt_all, lse_i, lse_t, lse_i_all, lse_t_all = ctx.saved_tensors
-        n_loc, D = img.shape
-        N, off = ctx.N, ctx.off
         gout = _f32c(gout.reshape(1))
-        dimg = torch.empty_like(img)
-        dtxt = torch.empty_like(txt)
-        dscale = torch.zeros(1, device=img.device, dtype=torch.float32)
-        coef = 1.0 / (2.0 * N)
-        call("mmg_clip_rows_bwd_fused", ptr(img), ptr(txt_all), ptr(scale), ptr(lse_i), ptr(lse_t_all), ptr(gout),
-             coef, n_loc, N, D, off, ptr(dimg), ptr(dscale), stream())
-        call("mmg_clip_rows_bwd_fused", ptr(txt), ptr(img_all), ptr(scale), ptr(lse_t), ptr(lse_i_all), ptr(gout),
-             coef, n_loc, N, D, off, ptr(dtxt), None, stream())
-        return dimg, dtxt, dscale.reshape(()), None
+        coef = 1.0 / (2.0 * ctx.N)
+        dimg, dscale = ctx.be.rows_backward(img, txt_all, scale, lse_i, lse_t_all, gout, coef, ctx.off, True)
+        dtxt, _ = ctx.be.rows_backward(txt, img_all, scale, lse_t, lse_i_all, gout, coef, ctx.off, False)
+        return dimg, dtxt, dscale.reshape(()), None, None
 
 
-def fused_clip_loss(image_embeddings, text_embeddings, logit_scale, comm=None):
+def fused_clip_loss(image_embeddings, text_embeddings, logit_scale, comm=None, _backend=None):
     """CLIPLoss on normalised embeddings; `logit_scale` is the already exponentiated scale (a tensor)."""
-    return FusedClipLoss.apply(image_embeddings, text_embeddings, logit_scale, comm)
+    return FusedClipLoss.apply(image_embeddings, text_embeddings, logit_scale, comm, _backend)

@@ -1,0 +1,111 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel choreography: embedding all-gather, LSE all-gather, locally
+complete gradients, summed parameter gradients.  The device arithmetic is replaced by the CPU oracle through the
+test-only backend hook of FusedClipLoss; everything else (Comm, GradSync, the autograd Function) is the product code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleHeadBackend:
+    @staticmethod
+    def rows_forward(x_loc, y_all, scale, diag_off):
+        from oracle import clip_oracle as O
+        lse, pos, _ = O.sharded_rows(x_loc, y_all, scale, diag_off)
+        return lse, pos
+
+    @staticmethod
+    def loss_sum(lse_i, pos_i, lse_t, pos_t, coef):
+        return (coef * ((lse_i - pos_i).sum() + (lse_t - pos_t).sum())).reshape(1)
+
+    @staticmethod
+    def rows_backward(x_loc, y_all, scale, lse_row, lse_col, gout, coef, diag_off, want_dscale):
+        from oracle import clip_oracle as O
+        dx, ds = O.sharded_rows_grad(x_loc, y_all, scale, lse_row, lse_col, coef * gout, diag_off)
+        return dx, ds.reshape(1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, golden, q):
+    for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from mmgclip import distributed, head
+    from oracle import clip_oracle as O
+    comm = distributed.init_from_env("gloo")
+    assert comm.rank == rank and comm.world_size == world
+    g = np.load(golden)
+    img_all, txt_all = torch.from_numpy(g["img"]), torch.from_numpy(g["txt"])
+    N = img_all.shape[0]
+    nl = N // world
+    sl = slice(rank * nl, (rank + 1) * nl)
+    # a tiny trainable "tower" per side so parameter gradients exist: shared weights, different data per rank
+    torch.manual_seed(0)
+    w_img = torch.nn.Parameter(torch.eye(img_all.shape[1]) + 0.01 * torch.randn(img_all.shape[1], img_all.shape[1]))
+    ls = torch.nn.Parameter(torch.tensor(float(g["logit_scale_param"])))
+    img = (img_all[sl] @ w_img.t())
+    txt = txt_all[sl].clone().requires_grad_(True)
+    ie, te = O.l2_normalize(img), O.l2_normalize(txt)
+    loss = head.fused_clip_loss(ie, te, ls.exp(), comm, OracleHeadBackend)
+    loss.backward()
+    sync = distributed.GradSync(comm, arenas=(), extra_params=[w_img, ls])
+    sync.finish()
+    # unsharded reference on every rank
+    w2 = w_img.detach().clone().requires_grad_(True)
+    ls2 = ls.detach().clone().requires_grad_(True)
+    t2 = txt_all.clone().requires_grad_(True)
+    out = O.forward_tail(img_all @ w2.t(), t2, ls2)
+    ref, _ = O.clip_loss(out["logits_per_image"], out["logits_per_text"])
+    ref.backward()
+    res = dict(rank=rank, loss=float(loss), ref=float(ref),
+               dw=float((w_img.grad - w2.grad).abs().max() / w2.grad.abs().max()),
+               dls=float((ls.grad - ls2.grad).abs() / ls2.grad.abs()),
+               dtxt=float((txt.grad - t2.grad[sl]).abs().max() / t2.grad.abs().max()))
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_global_batch_loss_and_grad_sync_gloo(golden_dir, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, os.path.join(golden_dir, "g2_head_n32.npz"), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in results:
+        assert abs(r["loss"] - r["ref"]) < 2e-6 * abs(r["ref"]), r          # identical global loss on every rank
+        assert r["dw"] < 1e-4 and r["dls"] < 1e-4 and r["dtxt"] < 1e-4, r    # summed grads == unsharded grads
+
+
+def test_comm_none_is_local_batch(golden_dir):
+    """comm=None reproduces the reference's local-batch CLIPLoss exactly (P = 1 special case)."""
+    for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from mmgclip import head
+    g = np.load(os.path.join(golden_dir, "g2_head_n8.npz"))
+    ie, te = torch.from_numpy(g["image_embeddings"]), torch.from_numpy(g["text_embeddings"])
+    loss = head.fused_clip_loss(ie, te, torch.from_numpy(g["scale"]), None, OracleHeadBackend)
+    assert abs(float(loss) - float(g["clip_loss"])) < 2e-6 * abs(float(g["clip_loss"])) + 2e-6
