@@ -13,25 +13,36 @@
 #include "common.h"
 
 #define DW_TW 32
-#define DW_TH 16
+#define DW_TH 8
 #define DW_CB 32
 #define DW_COLS (DW_TW + 6)
 #define DW_ROWS (DW_TH + 6)
 #define DW_ROWD (DW_COLS * (DW_CB / 2) + 16)   // dwords per LDS row; +16 keeps rows r, r+1 on disjoint bank halves
+// DW_TH = 8 keeps the tile at 34 KiB so four workgroups share a CU (latency hiding for the LDS-read / FMA phases)
 
-// stage the halo tile of image n (tile origin h0,w0; channel slab c0) into LDS, zero outside the image
+// stage the halo tile of image n (tile origin h0,w0; channel slab c0) into LDS, zero outside the image.
+// All of a lane's 16-byte loads are issued before the first LDS store: one memory latency per tile instead of one per
+// chunk (the chunk-by-chunk loop made staging 3x longer than the 49-tap arithmetic).
 __device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ x, unsigned* tile, int n, int H, int W, int C, int h0,
                                          int w0, int c0) {
     constexpr int CHUNKS = DW_ROWS * DW_COLS * (DW_CB / 8);
-    for (int idx = threadIdx.x; idx < CHUNKS; idx += 256) {
+    constexpr int ITERS = (CHUNKS + 255) / 256;
+    uint4 v[ITERS];
+    int dst[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = it * 256 + threadIdx.x;
         const int ch = idx & 3, pix = idx >> 2;
         const int col = pix % DW_COLS, row = pix / DW_COLS;
         const int gh = h0 - 3 + row, gw = w0 - 3 + col;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gh >= 0 && gh < H && gw >= 0 && gw < W)
-            v = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + gh) * W + gw) * C + c0 + ch * 8);
-        *reinterpret_cast<uint4*>(tile + row * DW_ROWD + col * (DW_CB / 2) + ch * 4) = v;
+        v[it] = make_uint4(0, 0, 0, 0);
+        dst[it] = idx < CHUNKS ? row * DW_ROWD + col * (DW_CB / 2) + ch * 4 : -1;
+        if (idx < CHUNKS && gh >= 0 && gh < H && gw >= 0 && gw < W)
+            v[it] = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + gh) * W + gw) * C + c0 + ch * 8);
     }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+        if (dst[it] >= 0) *reinterpret_cast<uint4*>(tile + dst[it]) = v[it];
 }
 
 template <bool FLIP>
@@ -57,43 +68,54 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restric
 #pragma unroll 1
     for (int pass = 0; pass < DW_TH / 4; ++pass) {
         const int oh = pass * 4 + r4;
+        const int gh = h0 + oh;
+        // the residual-gradient operand of this pass is fetched first: its latency hides under the 49-tap loop
+        unsigned addv[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int gw = w0 + strip * 8 + p;
+            addv[p] = (add && gh < H && gw < W) ? *reinterpret_cast<const unsigned*>(add + (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp) : 0u;
+        }
         float a0[8], a1[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) { a0[p] = b0; a1[p] = b1; }
-#pragma unroll 1
-        for (int kh = 0; kh < 7; ++kh) {
-            const unsigned* rowp = tile + (oh + kh) * DW_ROWD + (strip * 8) * (DW_CB / 2) + cp;
-            float i0[14], i1[14];
-#pragma unroll
-            for (int q = 0; q < 14; ++q) {
-                const unsigned v = rowp[q * (DW_CB / 2)];
-                i0[q] = bf2f_lo(v);
-                i1[q] = bf2f_hi(v);
-            }
-#pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-                const float2 wv = *reinterpret_cast<const float2*>(ws + (kh * 7 + kw) * DW_CB + 2 * cp);
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    a0[p] = fmaf(wv.x, i0[p + kw], a0[p]);
-                    a1[p] = fmaf(wv.y, i1[p + kw], a1[p]);
-                }
-            }
+        // software pipeline over the 7 kernel rows, two named register sets (A/B) in a ROLLED loop of row pairs: row
+        // kh+1 (inputs + taps) is read from LDS while row kh is consumed.  (Fully unrolled, hipcc hoists every row's
+        // reads to the top and spills.)
+        unsigned inA[14], inB[14];
+        float2 wA[7], wB[7];
+#define DW_LOAD_ROW(IN, WT, KH)                                                                          \
+        {                                                                                                \
+            const unsigned* rowp_ = tile + (oh + (KH)) * DW_ROWD + (strip * 8) * (DW_CB / 2) + cp;       \
+            _Pragma("unroll") for (int q = 0; q < 14; ++q) IN[q] = rowp_[q * (DW_CB / 2)];               \
+            _Pragma("unroll") for (int kw = 0; kw < 7; ++kw)                                             \
+                WT[kw] = *reinterpret_cast<const float2*>(ws + ((KH) * 7 + kw) * DW_CB + 2 * cp);        \
         }
-        const int gh = h0 + oh;
+#define DW_FMA_ROW(IN, WT)                                                                               \
+        _Pragma("unroll") for (int kw = 0; kw < 7; ++kw) {                                               \
+            _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                              \
+                a0[p] = fmaf(WT[kw].x, bf2f_lo(IN[p + kw]), a0[p]);                                      \
+                a1[p] = fmaf(WT[kw].y, bf2f_hi(IN[p + kw]), a1[p]);                                      \
+            }                                                                                            \
+        }
+        DW_LOAD_ROW(inA, wA, 0)
+#pragma unroll 1
+        for (int kh = 0; kh < 6; kh += 2) {
+            DW_LOAD_ROW(inB, wB, kh + 1)
+            DW_FMA_ROW(inA, wA)
+            DW_LOAD_ROW(inA, wA, kh + 2)
+            DW_FMA_ROW(inB, wB)
+        }
+        DW_FMA_ROW(inA, wA)
+#undef DW_LOAD_ROW
+#undef DW_FMA_ROW
         if (gh < H) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int gw = w0 + strip * 8 + p;
                 if (gw < W) {
                     const size_t off = (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp;
-                    float v0 = a0[p], v1 = a1[p];
-                    if (add) {
-                        const unsigned r = *reinterpret_cast<const unsigned*>(add + off);
-                        v0 += bf2f_lo(r);
-                        v1 += bf2f_hi(r);
-                    }
-                    *reinterpret_cast<unsigned*>(y + off) = pack2bf(v0, v1);
+                    *reinterpret_cast<unsigned*>(y + off) = pack2bf(a0[p] + bf2f_lo(addv[p]), a1[p] + bf2f_hi(addv[p]));
                 }
             }
         }
@@ -101,15 +123,16 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restric
 }
 
 // dw[k][c] += sum_{n,h,w} x[n, h+kh-3, w+kw-3, c] * dy[n,h,w,c] ;  dbias[c] += sum dy
+// A workgroup owns one 32-channel slab and walks (image, tile) work items with a grid stride, keeping the 49 taps x 2
+// channels of every lane in registers across items, so the LDS / global atomic reduction is paid once per workgroup
+// (it dominated the first version on the small late-stage feature maps).
 __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                float* __restrict__ dw, float* __restrict__ dbias, int N,
-                                                               int H, int W, int C, int tiles_w) {
+                                                               int H, int W, int C, int tiles_w, int tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
     unsigned* tile = smem_u;
-    float* red = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD);    // [50][32]
-    const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+    float* red = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD);    // [4 waves][50][32]
     const int c0 = blockIdx.y * DW_CB;
-    const int h0 = th * DW_TH, w0 = tw * DW_TW;
     const int cp = threadIdx.x & 15, r4 = (threadIdx.x >> 4) & 3, strip = threadIdx.x >> 6;
 
     float d0[49], d1[49];
@@ -117,7 +140,10 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_kernel(const bf16_t* __r
     for (int k = 0; k < 49; ++k) { d0[k] = 0.f; d1[k] = 0.f; }
     float sb0 = 0.f, sb1 = 0.f;
 
-    for (int n = blockIdx.z; n < N; n += gridDim.z) {
+    for (int item = blockIdx.x; item < N * tiles; item += gridDim.x) {
+        const int n = item / tiles, tl = item - n * tiles;
+        const int tw = tl % tiles_w, th = tl / tiles_w;
+        const int h0 = th * DW_TH, w0 = tw * DW_TW;
         __syncthreads();
         dw_stage(x, tile, n, H, W, C, h0, w0, c0);
         __syncthreads();
@@ -157,19 +183,28 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_kernel(const bf16_t* __r
             }
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 50 * DW_CB; i += 256) red[i] = 0.f;
+    // reduce over the four row groups of a wave with shuffles, then over the four waves through LDS (plain stores, no
+    // same-address LDS atomics: 16 lanes hammering one word serialised the first version), then one global atomic per tap
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 49; ++k) {
-        atomicAdd(&red[k * DW_CB + 2 * cp], d0[k]);
-        atomicAdd(&red[k * DW_CB + 2 * cp + 1], d1[k]);
+        d0[k] += __shfl_xor(d0[k], 16, 64); d0[k] += __shfl_xor(d0[k], 32, 64);
+        d1[k] += __shfl_xor(d1[k], 16, 64); d1[k] += __shfl_xor(d1[k], 32, 64);
     }
-    atomicAdd(&red[49 * DW_CB + 2 * cp], sb0);
-    atomicAdd(&red[49 * DW_CB + 2 * cp + 1], sb1);
+    sb0 += __shfl_xor(sb0, 16, 64); sb0 += __shfl_xor(sb0, 32, 64);
+    sb1 += __shfl_xor(sb1, 16, 64); sb1 += __shfl_xor(sb1, 32, 64);
+    if (r4 == 0) {
+        float* rw = red + strip * 50 * DW_CB;
+#pragma unroll
+        for (int k = 0; k < 49; ++k) *reinterpret_cast<float2*>(rw + k * DW_CB + 2 * cp) = make_float2(d0[k], d1[k]);
+        *reinterpret_cast<float2*>(rw + 49 * DW_CB + 2 * cp) = make_float2(sb0, sb1);
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < 49 * DW_CB; i += 256) atomicAdd(dw + (size_t)(i / DW_CB) * C + c0 + (i % DW_CB), red[i]);
-    if (dbias && threadIdx.x < DW_CB) atomicAdd(dbias + c0 + threadIdx.x, red[49 * DW_CB + threadIdx.x]);
+    for (int i = threadIdx.x; i < 50 * DW_CB; i += 256) {
+        const float v = red[i] + red[50 * DW_CB + i] + red[2 * 50 * DW_CB + i] + red[3 * 50 * DW_CB + i];
+        if (i < 49 * DW_CB) atomicAdd(dw + (size_t)(i / DW_CB) * C + c0 + (i % DW_CB), v);
+        else if (dbias) atomicAdd(dbias + c0 + (i - 49 * DW_CB), v);
+    }
 }
 
 static int dw_check(const char* who, int n, int H, int W, int C) {
@@ -206,15 +241,15 @@ MMG_API int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* d
     if (dw_check("mmg_dwconv7_wgrad", n, H, W, C)) return 1;
     MMG_CHECK_ARG(x && dy && dw, "mmg_dwconv7_wgrad: null pointer");
     const int tiles_w = cdiv(W, DW_TW), tiles_h = cdiv(H, DW_TH);
-    const size_t shm = (size_t)DW_ROWS * DW_ROWD * 4 + 50 * DW_CB * 4;
-    // enough workgroups to fill the chip, but few enough image-slices that the tap registers amortise the atomics
-    int zs = 1;
-    const int per_img = tiles_w * tiles_h * (C / DW_CB);
-    while (zs < n && per_img * zs < 1024) zs <<= 1;
-    if (zs > n) zs = n;
+    const size_t shm = (size_t)DW_ROWS * DW_ROWD * 4 + 4 * 50 * DW_CB * 4;
+    // ~1024 workgroups in total (4 per CU), each walking its share of the (image, tile) items of one channel slab
+    const int tiles = tiles_w * tiles_h, slabs = C / DW_CB;
+    int per_slab = 1024 / slabs;
+    if (per_slab < 1) per_slab = 1;
+    if (per_slab > n * tiles) per_slab = n * tiles;
     mmg_allow_lds(dwconv7_wgrad_kernel, shm);
-    hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3(tiles_w * tiles_h, C / DW_CB, zs), dim3(256), shm, stream,
-                       (const bf16_t*)x, (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w);
+    hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3(per_slab, slabs), dim3(256), shm, stream, (const bf16_t*)x,
+                       (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w, tiles);
     MMG_LAUNCH_CHECK("mmg_dwconv7_wgrad");
     return 0;
 }

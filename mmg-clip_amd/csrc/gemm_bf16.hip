@@ -19,6 +19,7 @@
 // The weight-gradient kernel reads both operands with ds_read_b64_tr_b16 (hardware transpose) because the
 // reduction index (the row m) is the slow index of both inputs.
 #include "common.h"
+#include <stdlib.h>
 
 #define GEMM_THREADS 256
 
@@ -51,19 +52,19 @@ __device__ __forceinline__ int swz(int r) {
 }
 
 // Stage ROWS x BK bf16 (rows row0.. of G, clamped to rows_total-1) into a lane-linear LDS tile.
-template <int ROWS, int BK>
+template <int ROWS, int BK, int THREADS = GEMM_THREADS>
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ G, int ld, int row0, int rows_total, int k0,
                                            char* lds_tile, int tid) {
     constexpr int CPR = BK / 8;
     constexpr int NCH = ROWS * CPR;
 #pragma unroll
-    for (int it = 0; it < (NCH + GEMM_THREADS - 1) / GEMM_THREADS; ++it) {
-        const int p = it * GEMM_THREADS + tid;
-        if (NCH % GEMM_THREADS == 0 || p < NCH) {
+    for (int it = 0; it < (NCH + THREADS - 1) / THREADS; ++it) {
+        const int p = it * THREADS + tid;
+        if (NCH % THREADS == 0 || p < NCH) {
             const int r = p / CPR, s = p % CPR;
             const int c = s ^ swz<BK>(r);
             const int gr = min(row0 + r, rows_total - 1);
-            glds16(G + (size_t)gr * ld + k0 + c * 8, lds_tile + (size_t)(it * GEMM_THREADS + (tid & ~63)) * 16);
+            glds16(G + (size_t)gr * ld + k0 + c * 8, lds_tile + (size_t)(it * THREADS + (tid & ~63)) * 16);
         }
     }
 }
@@ -79,15 +80,87 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
 }
 
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmNT g) {
-    constexpr int MI = BM / 32, NI = BN / 32;      // 16x16 fragments per wave (wave tile = BM/2 x BN/2)
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int LDCS = BN + 4;                    // fp32 staging pitch
+// One output row segment of 8 columns: staged fp32 accumulators -> bias / activation / layer scale / residual -> store.
+__device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* crow, int gr, int gc, const float* bias,
+                                                const float* cs, const uint4 res, const uint4 aux, bool want_aux) {
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(crow);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(crow + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], g.alpha, bias[e]);
+    if (g.epi == EPI_GELU || g.epi == EPI_RELU) {
+        if (g.aux_out) {
+            uint4 o;
+            o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+            *reinterpret_cast<uint4*>(g.aux_out + (size_t)gr * g.ldao + gc) = o;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
+    } else if (want_aux) {
+        const unsigned hw[4] = {aux.x, aux.y, aux.z, aux.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
+            if (g.epi == EPI_DGELU) {
+                v[2 * e] *= gelu_grad_f(h0);
+                v[2 * e + 1] *= gelu_grad_f(h1);
+            } else {
+                v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;
+                v[2 * e + 1] = h1 > 0.f ? v[2 * e + 1] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= cs[e];
+    if (g.residual) {
+        const unsigned rw[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
+    }
+    if (g.out_f32) {
+        float* dst = reinterpret_cast<float*>(g.C) + (size_t)gr * g.ldc + gc;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        uint4 o;
+        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (size_t)gr * g.ldc + gc) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel.  WAVES_M x 2 waves, wave tile 64 x BN/2, BM = 64 * WAVES_M, NST staging buffers.
+//   <128, BN, BK, 2, 2> : 256 threads, two workgroups per CU (small / skinny problems, K % 64 != 0)
+//   <256, 128, 64, 4, 3>: 512 threads, one workgroup per CU, two K tiles in flight across the barrier
+//                         (counted s_waitcnt vmcnt + raw s_barrier; a __syncthreads() would drain the LDS-DMA queue)
+// The main loop is unrolled over the NST buffers so that every LDS address is "per-thread constant + immediate" and
+// every global source address is "uniform 64-bit base (SGPR, advanced per K tile) + per-thread 32-bit offset":
+// no vector ALU work per K tile besides the MFMAs (measured before: ~90 non-MFMA instructions per tile and wave).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int NST>
+__global__ __launch_bounds__(WAVES_M * 128, 2) void gemm_nt_kernel(const GemmNT g) {
+    constexpr int THREADS = WAVES_M * 128;
+    constexpr int MI = 4, NI = BN / 32;                  // 16x16 fragments per wave (wave tile 64 x BN/2)
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int CPR = BK / 8;                           // 16-byte chunks per staged row
+    constexpr int A_IT = (BM * CPR + THREADS - 1) / THREADS, B_IT = (BN * CPR + THREADS - 1) / THREADS;
+    constexpr bool B_RAGGED = (BN * CPR) % THREADS != 0;  // last B pass only on the first waves (BN = 96, BK = 32)
+    constexpr int LDCS = BN + 4;                          // fp32 staging pitch
+    static_assert(BM == 64 * WAVES_M, "wave tile is 64 rows");
+    static_assert(!(NST > 2 && B_RAGGED), "counted vmcnt needs the same number of loads in every wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // stage s: A tile at s*(A_BYTES+B_BYTES), B tile right behind it
-#define NT_AS(s) (smem + (s) * (A_BYTES + B_BYTES))
-#define NT_BS(s) (smem + (s) * (A_BYTES + B_BYTES) + A_BYTES)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -102,11 +175,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmNT g
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // epilogue geometry: each thread owns 8 consecutive columns of a row, PASSES rows per thread.  Its per-column
-    // vectors are fetched now so their latency hides under the main loop.
-    constexpr int TPR = BN / 8;                       // threads per row
-    constexpr int RPP = GEMM_THREADS / TPR;           // rows per pass
-    constexpr int PASSES = (BM + RPP - 1) / RPP;
+    // epilogue geometry: each thread owns 8 consecutive columns of a row; per-column vectors are fetched now
+    constexpr int TPR = BN / 8;                           // threads per row
+    constexpr int RPP = THREADS / TPR;                    // rows per pass
+    constexpr int QP = (64 + RPP - 1) / RPP;              // passes per 64-row slab (= one wave row)
+    constexpr int PASSES = WAVES_M * QP;
     const int tr = tid / TPR, tc = (tid % TPR) * 8;
     const int gc = n0 + tc;
     const bool col_ok = (tr < RPP) && (gc < g.N);
@@ -117,124 +190,129 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(const GemmNT g
         cs[e] = (col_ok && g.colscale) ? g.colscale[gc + e] : 1.f;
     }
 
+    // ---- per-thread constants of the staging (global byte offsets inside the tile, rows clamped) -----------------
+    unsigned a_off[A_IT], b_off[B_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int p = it * THREADS + tid, r = p / CPR, sl = p % CPR;
+        const int gr = min(m0 + r, g.M - 1) - m0;
+        a_off[it] = (unsigned)(gr * g.lda + (sl ^ swz<BK>(r)) * 8) * 2u;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int p = it * THREADS + tid, r = p / CPR, sl = p % CPR;
+        const int gr = min(n0 + min(r, BN - 1), g.N - 1) - n0;
+        b_off[it] = (unsigned)(gr * g.ldb + (sl ^ swz<BK>(r)) * 8) * 2u;
+    }
+    const bool b_last = !B_RAGGED || ((B_IT - 1) * THREADS + tid < BN * CPR);
+    const char* a_base = reinterpret_cast<const char*>(g.A + (size_t)m0 * g.lda);   // uniform; advanced by BK per tile
+    const char* b_base = reinterpret_cast<const char*>(g.B + (size_t)n0 * g.ldb);
+    char* lds_wave = smem + (tid & ~63) * 16;                                       // wave-uniform LDS-DMA base
+
+    auto stage = [&](int buf, int kt) {
+        const char* ab = a_base + (size_t)kt * (BK * 2);
+        const char* bb = b_base + (size_t)kt * (BK * 2);
+        char* la = lds_wave + buf * STAGE;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) glds16(ab + a_off[it], la + it * THREADS * 16);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            if (it + 1 < B_IT || b_last) glds16(bb + b_off[it], la + A_BYTES + it * THREADS * 16);
+    };
+
+    // ---- per-thread constants of the fragment reads: row byte offset + swizzled chunk for ks = 0 and 1 ----------
+    int a_frag[BK / 32], b_frag[BK / 32];
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+        const int ra = wm * 64 + li, rb = wn * (BN / 2) + li;      // rows of fragment 0; fragment i adds 16 rows
+        a_frag[ks] = ra * (BK * 2) + (((4 * ks + lg) ^ swz<BK>(ra)) << 4);
+        b_frag[ks] = A_BYTES + rb * (BK * 2) + (((4 * ks + lg) ^ swz<BK>(rb)) << 4);
+    }
+    // (rows r and r + 16 share swz(r) for BK = 64 [r & 7]; for BK = 32 swz depends on (r >> 2) & 3, unchanged by +16)
+
     const int nk = g.K / BK;
-    stage_rows<BM, BK>(g.A, g.lda, m0, g.M, 0, NT_AS(0), tid);
-    stage_rows<BN, BK>(g.B, g.ldb, n0, g.N, 0, NT_BS(0), tid);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            stage_rows<BM, BK>(g.A, g.lda, m0, g.M, (kt + 1) * BK, NT_AS(cur ^ 1), tid);
-            stage_rows<BN, BK>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, NT_BS(cur ^ 1), tid);
-        }
-        const char* a_t = NT_AS(cur);
-        const char* b_t = NT_BS(cur);
+    constexpr int LOADS = A_IT + B_IT;
 #pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-            bf16x8 af[MI], bfr[NI];
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s, s);
+
+    for (int kt0 = 0; kt0 < nk; kt0 += NST) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = read_frag<BK>(a_t, wm * (BM / 2) + i * 16 + li, 4 * ks + lg);
+        for (int s = 0; s < NST; ++s) {
+            const int kt = kt0 + s;
+            if (kt < nk) {
+                // tile kt has landed once at most the NST-2 younger tiles are still outstanding (in-order retirement)
+                if (NST > 2 && kt + (NST - 2) < nk) wait_vmcnt<(NST > 2 ? (NST - 2) * LOADS : 0)>();
+                else wait_vmcnt<0>();
+                if (NST > 2) __builtin_amdgcn_s_barrier(); else __syncthreads();
+                if (kt + NST - 1 < nk) stage((s + NST - 1) % NST, kt + NST - 1);
+                const char* buf = smem + s * STAGE;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = read_frag<BK>(b_t, wn * (BN / 2) + j * 16 + li, 4 * ks + lg);
+                for (int ks = 0; ks < BK / 32; ++ks) {
+                    bf16x8 af[MI], bfr[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(buf + a_frag[ks] + i * 16 * BK * 2);
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(buf + b_frag[ks] + j * 16 * BK * 2);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+            }
         }
     }
 
     // issue EVERY global read of the epilogue (residual / saved pre-activation rows of all passes) before the
-    // accumulators go through LDS: with two workgroups per CU nothing else would hide their latency pass by pass.
+    // accumulators go through LDS, so their latency overlaps the staging instead of being paid pass by pass.
     uint4 res_v[PASSES], aux_v[PASSES];
     const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DRELU);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-        const int gr = m0 + tr + p * RPP;
-        const bool ok = col_ok && (tr + p * RPP < BM) && (gr < g.M);
+        const int rl = tr + (p % QP) * RPP;
+        const int gr = m0 + (p / QP) * 64 + rl;
+        const bool ok = col_ok && (rl < 64) && (gr < g.M);
         res_v[p] = make_uint4(0, 0, 0, 0);
         aux_v[p] = make_uint4(0, 0, 0, 0);
         if (ok && g.residual) res_v[p] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
         if (ok && want_aux) aux_v[p] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
     }
-    __syncthreads();   // all fragment reads done before the staging buffers become the C tile
-
-    // accumulators -> LDS (row = m, 4 consecutive n per lane)
+    // accumulators -> LDS -> coalesced 16-byte row segments, one 64-row slab (= one wave row) at a time
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int q = 0; q < WAVES_M; ++q) {
+        __syncthreads();   // fragment reads (q = 0) / the previous slab's reads are done
+        if (wm == q) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int r = wm * (BM / 2) + i * 16 + li;
-            const int c = wn * (BN / 2) + j * 16 + 4 * lg;
-            *reinterpret_cast<f32x4*>(Cs + r * LDCS + c) = acc[i][j];
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    *reinterpret_cast<f32x4*>(Cs + (i * 16 + li) * LDCS + wn * (BN / 2) + j * 16 + 4 * lg) = acc[i][j];
         }
-    __syncthreads();
-
-    if (!col_ok) return;
+        __syncthreads();
+        if (col_ok) {
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int r = tr + p * RPP;
-        const int gr = m0 + r;
-        if (r >= BM || gr >= g.M) continue;
-        float v[8];
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * LDCS + tc);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * LDCS + tc + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], g.alpha, bias[e]);
-        if (g.epi == EPI_GELU || g.epi == EPI_RELU) {
-            if (g.aux_out) {
-                uint4 o;
-                o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-                *reinterpret_cast<uint4*>(g.aux_out + (size_t)gr * g.ldao + gc) = o;
+            for (int hp = 0; hp < QP; ++hp) {
+                const int rl = tr + hp * RPP;
+                const int gr = m0 + q * 64 + rl;
+                if (rl < 64 && gr < g.M)
+                    nt_epilogue_row(g, Cs + rl * LDCS + tc, gr, gc, bias, cs, res_v[q * QP + hp], aux_v[q * QP + hp], want_aux);
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
-        } else if (want_aux) {
-            const unsigned hw[4] = {aux_v[p].x, aux_v[p].y, aux_v[p].z, aux_v[p].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
-                if (g.epi == EPI_DGELU) {
-                    v[2 * e] *= gelu_grad_f(h0);
-                    v[2 * e + 1] *= gelu_grad_f(h1);
-                } else {
-                    v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;
-                    v[2 * e + 1] = h1 > 0.f ? v[2 * e + 1] : 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= cs[e];
-        if (g.residual) {
-            const unsigned rw[4] = {res_v[p].x, res_v[p].y, res_v[p].z, res_v[p].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
-        }
-        if (g.out_f32) {
-            float* dst = reinterpret_cast<float*>(g.C) + (size_t)gr * g.ldc + gc;
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-            uint4 o;
-            o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (size_t)gr * g.ldc + gc) = o;
         }
     }
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int WAVES_M, int NST>
 static void launch_nt(GemmNT& g, hipStream_t stream) {
     g.tiles_m = cdiv(g.M, BM);
     g.tiles_n = cdiv(g.N, BN);
-    const size_t stage = 2 * (size_t)(BM * BK * 2 + BN * BK * 2);
-    const size_t cs = (size_t)BM * (BN + 4) * 4;
+    const size_t stage = (size_t)NST * (BM * BK * 2 + BN * BK * 2);
+    const size_t cs = (size_t)64 * (BN + 4) * 4;
     const size_t shm = stage > cs ? stage : cs;
-    mmg_allow_lds(gemm_nt_kernel<BM, BN, BK>, shm);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK>), dim3(g.tiles_m * g.tiles_n), dim3(GEMM_THREADS), shm, stream, g);
+    mmg_allow_lds(gemm_nt_kernel<BM, BN, BK, WAVES_M, NST>, shm);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WAVES_M, NST>), dim3(g.tiles_m * g.tiles_n), dim3(WAVES_M * 128), shm,
+                       stream, g);
 }
 
 MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -258,11 +336,14 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.bias = bias; g.colscale = colscale;
     g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = (const bf16_t*)aux_in; g.ldai = ldai;
     g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha;
-    const bool k64 = (K % 64 == 0);
+    static const int force_bk = getenv("MMG_GEMM_BK") ? atoi(getenv("MMG_GEMM_BK")) : 0;   // tuning knobs
+    static const int use_big = getenv("MMG_GEMM_V2") ? atoi(getenv("MMG_GEMM_V2")) : 1;
+    const bool k64 = (K % 64 == 0) && force_bk != 32;
     // N tile: 96 when it divides N and 128 does not (ConvNeXt widths 96/192), else 128
     const bool n96 = (N % 128 != 0) && (N % 96 == 0);
-    if (n96) { if (k64) launch_nt<128, 96, 64>(g, stream); else launch_nt<128, 96, 32>(g, stream); }
-    else     { if (k64) launch_nt<128, 128, 64>(g, stream); else launch_nt<128, 128, 32>(g, stream); }
+    if (use_big && k64 && !n96 && M >= 4096 && K >= 512) launch_nt<256, 128, 64, 4, 3>(g, stream);
+    else if (n96) { if (k64) launch_nt<128, 96, 64, 2, 2>(g, stream); else launch_nt<128, 96, 32, 2, 2>(g, stream); }
+    else          { if (k64) launch_nt<128, 128, 64, 2, 2>(g, stream); else launch_nt<128, 128, 32, 2, 2>(g, stream); }
     MMG_LAUNCH_CHECK("mmg_gemm_nt_bf16");
     return 0;
 }
@@ -426,7 +507,8 @@ MMG_API int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, flo
     g.tiles1 = cdiv(N1, TN_T);
     g.tiles2 = cdiv(N2, TN_T);
     const int tiles = g.tiles1 * g.tiles2;
-    int chunks = 1024 / tiles;
+    static const int target_wgs = getenv("MMG_TN_WGS") ? atoi(getenv("MMG_TN_WGS")) : 512;
+    int chunks = target_wgs / tiles;
     if (chunks < 1) chunks = 1;
     const int max_chunks = cdiv(M, TN_BK);
     if (chunks > max_chunks) chunks = max_chunks;
