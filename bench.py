@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="image-text pairs per GPU")
     ap.add_argument("--image-size", type=int, default=1024)
     ap.add_argument("--seq-len", type=int, default=77)
-    ap.add_argument("--micro-batch", type=int, default=16)
+    ap.add_argument("--micro-batch", type=int, default=64)
     ap.add_argument("--variant", default="tiny", choices=["tiny", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -85,7 +85,8 @@ int mmg_clip_loss_reduce(const float* lse_a, const float* pos_a, const float* ls
 /* C[M,N] = epilogue( alpha * A[M,K] B[N,K]^T + bias )   A,B bf16 row-major (K contiguous), fp32 accumulate.
  * epilogue (in this order): + bias[N];  activation by `epi`:
  *     0 none | 1 GELU(erf) (aux_out, when given, receives the pre-activation) | 2 multiply by GELU'(aux_in)
- *     3 ReLU (aux_out as 1)  | 4 ReLU' (gate by aux_in > 0);
+ *     (aux_out, when given, receives GELU(aux_in): the activation rebuilt for the weight-gradient GEMM)
+ *     3 ReLU (aux_out as 1)  | 4 ReLU' (gate by aux_in > 0; aux_out as 2);
  * then * colscale[N] (ConvNeXt layer scale), + residual[M,N] (bf16); C is bf16 (out_f32 = 0) or fp32.
  * K % 32 == 0, N % 8 == 0, leading dimensions multiples of 8.
  * Replaces nn.Linear forward / data-gradient in HF BertLayer (reference call site mmgclip/networks/encoder.py:156),

@@ -100,17 +100,26 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
         for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
     } else if (want_aux) {
         const unsigned hw[4] = {aux.x, aux.y, aux.z, aux.w};
+        unsigned act[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
             if (g.epi == EPI_DGELU) {
-                v[2 * e] *= gelu_grad_f(h0);
-                v[2 * e + 1] *= gelu_grad_f(h1);
+                // the activation itself (needed by the weight-gradient GEMM of the same layer) shares cdf/pdf with
+                // its derivative: emitting it here replaces a separate read-modify-write pass over the [M,N] tensor
+                float c0, p0, c1, p1;
+                gelu_parts(h0, c0, p0);
+                gelu_parts(h1, c1, p1);
+                v[2 * e] *= fmaf(h0, p0, c0);
+                v[2 * e + 1] *= fmaf(h1, p1, c1);
+                act[e] = pack2bf(h0 * c0, h1 * c1);
             } else {
+                act[e] = pack2bf(fmaxf(h0, 0.f), fmaxf(h1, 0.f));
                 v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;
                 v[2 * e + 1] = h1 > 0.f ? v[2 * e + 1] : 0.f;
             }
         }
+        if (g.aux_out) *reinterpret_cast<uint4*>(g.aux_out + (size_t)gr * g.ldao + gc) = make_uint4(act[0], act[1], act[2], act[3]);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= cs[e];

@@ -175,10 +175,10 @@ class BertTower(nn.Module):
             x, qkv, ctx, lse, a, m1, r1, x1, hpre, f, m2, r2 = saved["layers"][i]
             df = K.layernorm_bwd(dx, f, m2, r2, lyr.output.LayerNorm.weight.data, A.g(p + "output.LayerNorm.weight"),
                                  A.g(p + "output.LayerNorm.bias"))
-            g = K.gelu(hpre)
+            g = torch.empty_like(hpre)                     # GELU(hpre), rebuilt by the same epilogue that applies GELU'
+            dh = L.gemm_nt(df, wc[f"{i}.wft"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
             L.gemm_tn_acc(df, g, A.g(p + "output.dense.weight"), colsum=A.g(p + "output.dense.bias"))
             del g
-            dh = L.gemm_nt(df, wc[f"{i}.wft"], epi=L.EPI_DGELU, aux_in=hpre)
             L.gemm_tn_acc(dh, x1, A.g(p + "intermediate.dense.weight"), colsum=A.g(p + "intermediate.dense.bias"))
             dx1 = L.gemm_nt(dh, wc[f"{i}.wit"], residual=df)          # + residual path of the FFN block
             del dh, df

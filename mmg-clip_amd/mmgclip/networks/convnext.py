@@ -80,7 +80,7 @@ class _TorchvisionLayout(nn.Module):
 class ConvNextTower(nn.Module):
     """pixels fp32 [n, Cin, H, W] in [0,1] (scale16=True applies the reference's 16-bit scaling) -> features [n, dims[-1]]."""
 
-    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=16):
+    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=64):
         super().__init__()
         self.variant, self.in_chans, self.scale16, self.micro_batch = variant, in_chans, scale16, micro_batch
         self.dims, self.depths = CONFIGS[variant]["dims"], CONFIGS[variant]["depths"]
@@ -192,10 +192,10 @@ class ConvNextTower(nn.Module):
                 blk = f[1 + 2 * si][bi]
                 key = f"{si}.{bi}"
                 x, d, mean, rstd, hpre = saved[key]
-                g = K.gelu(hpre)
+                g = torch.empty_like(hpre)                 # GELU(hpre), rebuilt by the same epilogue that applies GELU'
+                dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
                 L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
                 del g
-                dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre)
                 ln, _, _ = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=False)
                 L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
                 del ln

@@ -67,7 +67,7 @@ class ResNet50Encoder(nn.Module):
 class _ConvNextEncoder(ConvNextTower):
     VARIANT = "tiny"
 
-    def __init__(self, pretrained=None, image_features_dimension=None, in_chans=1, scale16=True, micro_batch=16, freeze=False):
+    def __init__(self, pretrained=None, image_features_dimension=None, in_chans=1, scale16=True, micro_batch=64, freeze=False):
         super().__init__(self.VARIANT, in_chans=in_chans, scale16=scale16, micro_batch=micro_batch)
         if isinstance(pretrained, str) and os.path.isfile(pretrained):
             sd = _load_state_file(pretrained)

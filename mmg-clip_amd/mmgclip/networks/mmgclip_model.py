@@ -49,7 +49,7 @@ class MMGCLIP(nn.Module):
             ie = self.config.networks.image_encoder
             self.image_encoder = getNetworkClass(enc_name)(
                 pretrained=_get(ie, "pretrained_path"), image_features_dimension=ie.image_features_dimension,
-                in_chans=_get(ie, "in_chans", 1), scale16=_get(ie, "scale16", True), micro_batch=_get(ie, "micro_batch", 16),
+                in_chans=_get(ie, "in_chans", 1), scale16=_get(ie, "scale16", True), micro_batch=_get(ie, "micro_batch", 64),
                 freeze=_get(ie, "freeze", False)).to(self.device)
             logger.info(f"Using {self.image_encoder.__class__.__name__}")
 

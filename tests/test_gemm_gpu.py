@@ -52,7 +52,9 @@ def test_nt_epilogues(dev):
     np.testing.assert_allclose(y.cpu().numpy(), (pre * cs + res.float()).cpu().numpy(), rtol=1e-4, atol=1e-3)
     # GELU backward: (a b^T) * gelu'(h)
     hh = _rand((M, N), dev, 1.0, 6)
-    y = linalg.gemm_nt(a, b, epi=linalg.EPI_DGELU, aux_in=hh, out_dtype=torch.float32)
+    act = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    y = linalg.gemm_nt(a, b, epi=linalg.EPI_DGELU, aux_in=hh, aux_out=act, out_dtype=torch.float32)
+    np.testing.assert_allclose(act.float().cpu().numpy(), torch.nn.functional.gelu(hh.float()).cpu().numpy(), rtol=1e-2, atol=1e-2)
     x = hh.float().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
     np.testing.assert_allclose(y.cpu().numpy(), ((a.float() @ b.float().t()) * x.grad).cpu().numpy(), rtol=1e-3, atol=1e-3)
