@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--variant", default="tiny", choices=["tiny", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--cpu-baseline-worker", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker is not None:
@@ -149,9 +150,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    comm = distributed.init_from_env("nccl") if world > 1 else None
+    comm = distributed.init_from_env(args.backend) if world > 1 else None
     rank = comm.rank if comm else 0
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     cfg, model, criterion, arenas = build(args, comm)
@@ -227,6 +228,15 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             out["roofline"] = linalg.PROFILE.summary(MFMA_BF16_PEAK_TFLOPS)
+            # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/collect_traffic.sh; the
+            # counters cannot be read from inside the process), corrected as MI355X_MICROARCH.md prescribes
+            tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) \
+                if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+            default_cmd = (args.batch, args.image_size, args.seq_len, args.micro_batch, args.variant, world) == (256, 1024, 77, 64, "tiny", 1)
+            if tfile and default_cmd and out["roofline"]:
+                t = json.load(open(os.path.join(ROOT, "profiles", tfile[-1])))
+                out["roofline"]["traffic"] = round(t["gemm_nt_kernel"]["hbm_bytes_per_launch"])
+                out["roofline"]["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile[-1]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

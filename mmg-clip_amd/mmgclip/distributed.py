@@ -25,7 +25,10 @@ class Comm:
         """[n, ...] -> [world*n, ...] in rank order (no autograd: gradients are formed locally, see head.FusedClipLoss)."""
         t = t.contiguous()
         out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-        dist.all_gather_into_tensor(out, t, group=self.group)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out, t, group=self.group)        # one RCCL all-gather, no staging copies
+        else:                                                            # gloo (CPU tests / single-GPU rehearsal)
+            dist.all_gather(list(out.split(t.shape[0], dim=0)), t, group=self.group)
         return out
 
     def all_reduce_sum(self, t):
@@ -41,8 +44,8 @@ def init_from_env(backend=None):
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         dist.init_process_group(backend=backend)
     return Comm()
 

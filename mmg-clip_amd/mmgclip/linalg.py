@@ -71,7 +71,7 @@ class _GemmProfile:
         return {"kernel": "gemm_nt_kernel (bf16 MFMA, all shapes of the step)", "bound": "mfma", "achieved": round(ach, 1),
                 "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4), "traffic": None,
                 "launches": n, "avg_launch_us": round(t_ms * 1000.0 / n, 1), "total_ms": round(t_ms, 2),
-                "algorithmic_gbytes_per_s": round(byts / (t_ms * 1e-3) / 1e9, 1)}
+                "algorithmic_bytes_per_launch": round(byts / n), "algorithmic_gbytes_per_s": round(byts / (t_ms * 1e-3) / 1e9, 1)}
 
 
 PROFILE = _GemmProfile()

@@ -1,0 +1,103 @@
+"""Two ranks sharing the one MI355X of the test box (gloo transport, HIP kernels): the global-batch training step of
+P = 2 ranks on halves of a batch must give the loss and the (summed) parameter gradients of one rank on the whole batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_DIR = os.path.join(ROOT, "mmg-clip_amd", "configs")
+OVERRIDES = ["networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_seqlen=77", "networks/dropout=dropout0",
+             "networks.image_encoder.micro_batch=4", "networks.image_encoder.image_size=64"]
+
+
+def _build_and_step(comm, batch):
+    from mmgclip import distributed
+    from mmgclip.config import compose
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks import bert
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    orig = bert.BertConfigLite.__init__
+
+    def small(self, **kw):
+        kw.setdefault("num_hidden_layers", 2)
+        kw.setdefault("vocab_size", 3000)
+        orig(self, **kw)
+    bert.BertConfigLite.__init__ = small
+    try:
+        torch.manual_seed(0)
+        model = MMGCLIP(compose(CFG_DIR, "train_binary_class_clf", OVERRIDES)).train()
+    finally:
+        bert.BertConfigLite.__init__ = orig
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("layer_scale"):
+                p.fill_(0.5)
+    crit = create_loss("CLIPLoss")(comm=comm)
+    out = model(batch, materialize_logits=False)
+    loss, _ = crit(**out)
+    extra = [p for n, p in model.named_parameters() if not (n.startswith("image_encoder.") or n.startswith("text_encoder."))]
+    sync = distributed.GradSync(comm, [model.image_encoder.arena, model.text_encoder.arena], extra)
+    if comm is not None:
+        model.image_encoder.post_backward_hook = sync.reduce_arena_async
+        model.text_encoder.post_backward_hook = sync.reduce_arena_async
+    loss.backward()
+    sync.finish()
+    torch.cuda.synchronize()
+    g_img = model.image_encoder.arena.grad.clone()
+    g_txt = model.text_encoder.arena.grad.clone()
+    g_proj = model.image_projection_layer.layer.weight.grad.clone()
+    return loss.item(), g_img.cpu(), g_txt.cpu(), g_proj.cpu()
+
+
+def _slice_batch(batch, sl):
+    from mmgclip.dataset.synthetic import TokenBatch
+    return {"image": batch["image"][sl].clone(), "text_tokens": TokenBatch({k: v[sl].clone() for k, v in batch["text_tokens"].items()})}
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mmgclip import distributed
+    from mmgclip.dataset.synthetic import synthetic_batch
+    comm = distributed.init_from_env("gloo")
+    batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=11)
+    n = 8 // world
+    loss, gi, gt, gp = _build_and_step(comm, _slice_batch(batch, slice(rank * n, (rank + 1) * n)))
+    q.put((rank, loss, gi.numpy(), gt.numpy(), gp.numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_on_the_whole_batch(dev):
+    from mmgclip.dataset.synthetic import synthetic_batch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=11)
+    loss, gi, gt, gp = _build_and_step(None, _slice_batch(batch, slice(0, 8)))
+    for rank, l2, gi2, gt2, gp2 in results:
+        assert abs(l2 - loss) < 2e-3 * abs(loss), (rank, l2, loss)               # bf16 towers see different micro-batches
+        for name, a, b in (("convnext", gi2, gi.numpy()), ("bert", gt2, gt.numpy()), ("proj", gp2, gp.numpy())):
+            cos = float(np.dot(a.ravel(), b.ravel()) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+            rel = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+            assert cos > 0.999 and rel < 5e-2, (rank, name, cos, rel)
+    # both ranks hold identical reduced gradients
+    assert np.array_equal(results[0][2], results[1][2]) and np.array_equal(results[0][3], results[1][3])

@@ -1,0 +1,40 @@
+#!/bin/bash
+# HBM traffic of every kernel of the default bench command, from rocprofv3 PMC counters collected in SEPARATE passes
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with trace domains) — run on the GPU box:
+#   bash tools/collect_traffic.sh gpurun_out/traffic
+# Writes $1/traffic.json (then copy it to profiles/rNN_traffic.json).  FETCH_SIZE is doubled (gfx950 counts 128-B
+# requests as 64 B on wide coalesced reads, MI355X_MICROARCH.md §HBM); WRITE_SIZE is exact for 16-B-per-lane stores.
+set -e
+OUT=${1:-gpurun_out/traffic}
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pmc_f /tmp/pmc_w
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python3 "$REPO/bench.py" --no-cpu-baseline --no-roofline > "$OUT/pass_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python3 "$REPO/bench.py" --no-cpu-baseline --no-roofline > "$OUT/pass_write.log" 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, collections, json, sys
+out = sys.argv[1]
+res = {}
+for tag, d in (("FETCH_SIZE", "/tmp/pmc_f"), ("WRITE_SIZE", "/tmp/pmc_w")):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == tag:
+            k = r["Kernel_Name"].split("(")[0].strip()
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])     # KiB
+    res[tag] = agg
+kernels = {}
+for k, (n, kb) in res["FETCH_SIZE"].items():
+    w = res["WRITE_SIZE"].get(k, [0, 0.0])
+    kernels[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * kb * 1024 / n, "write_bytes_per_launch": w[1] * 1024 / max(w[0], 1)}
+nt = {k: v for k, v in kernels.items() if "gemm_nt_kernel" in k}
+n = sum(v["launches"] for v in nt.values())
+tot = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in nt.values())
+summary = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-roofline",
+           "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE x1, KiB -> bytes",
+           "gemm_nt_kernel": {"launches": n, "hbm_bytes_per_launch": tot / n}, "kernels": kernels}
+json.dump(summary, open(out + "/traffic.json", "w"), indent=1)
+print(json.dumps(summary["gemm_nt_kernel"]))
+PY
