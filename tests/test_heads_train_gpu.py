@@ -1,0 +1,102 @@
+"""Projection heads vs the reference golden (g1) and a short end-to-end run of train.py's experiment on synthetic data."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+# heads run their matrix products on the bf16 MFMA path (fp32 accumulate): 8-bit mantissa inputs
+RTOL, ATOL = 3e-2, 3e-2
+
+
+def _t(a, dev, grad=False):
+    t = torch.from_numpy(np.asarray(a)).to(dev)
+    return t.requires_grad_(True) if grad else t
+
+
+def test_projection_heads_match_reference_golden(golden_dir, dev):
+    from mmgclip.networks.projection_controller import get_projection_head
+    g = np.load(os.path.join(golden_dir, "g1_projection.npz"))
+    x, gy = _t(g["x"], dev, True), _t(g["gy"], dev)
+    lin = get_projection_head("LinearProjectionLayer")(embedding_dim=96, projection_dim=64, dropout=0.5).to(dev)
+    lin.load_state_dict({"layer.weight": _t(g["linear.weight"], dev)})
+    y = lin(x)
+    y.backward(gy)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["linear.y"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["linear.dx"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(lin.layer.weight.grad.cpu().numpy(), g["linear.dweight"], rtol=RTOL, atol=2 * ATOL)
+
+    x = _t(g["x"], dev, True)
+    ml = get_projection_head("MultiLinearHead")(embedding_dim=96, projection_dim=[96, 64], dropout=0.0).to(dev).train()
+    ml.load_state_dict({f"layers.{i}.{k}": _t(g[f"multi.layers.{i}.{k}"], dev) for i in (0, 1) for k in ("weight", "bias")})
+    y = ml(x)
+    y.backward(gy)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["multi.y"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["multi.dx"], rtol=RTOL, atol=ATOL)
+    for i in (0, 1):
+        np.testing.assert_allclose(ml.layers[i].weight.grad.cpu().numpy(), g[f"multi.layers.{i}.dweight"], rtol=RTOL, atol=2 * ATOL)
+        np.testing.assert_allclose(ml.layers[i].bias.grad.cpu().numpy(), g[f"multi.layers.{i}.dbias"], rtol=RTOL, atol=2 * ATOL)
+
+    x = _t(g["x"], dev, True)
+    mlp = get_projection_head("MLPProjectionHead")(embedding_dim=96, projection_dim=64, dropout=0.0).to(dev).train()
+    mlp.load_state_dict({k[4:]: _t(g[k], dev) for k in g.files if k.startswith("mlp.") and not k.startswith("mlp.grad.") and k not in ("mlp.y", "mlp.dx")})
+    y = mlp(x)
+    y.backward(gy)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["mlp.y"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["mlp.dx"], rtol=2 * RTOL, atol=2 * ATOL)
+    for name, p in mlp.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["mlp.grad." + name], rtol=2 * RTOL, atol=4 * ATOL)
+
+
+def test_dropout_head_statistics(dev):
+    from mmgclip import ops
+    torch.manual_seed(0)
+    x = torch.ones(256, 512, device=dev, requires_grad=True)
+    y = ops.dropout(x, 0.2, True)
+    kept = (y > 0).float().mean().item()
+    assert abs(kept - 0.8) < 0.01 and abs(y.mean().item() - 1.0) < 0.02
+    y.sum().backward()
+    assert torch.equal((x.grad > 0), (y > 0)) and abs(x.grad.max().item() - 1.25) < 1e-6
+    assert ops.dropout(x, 0.2, False) is x
+
+
+def test_classifier_experiment_runs_like_the_reference_loop(dev, tmp_path, monkeypatch):
+    """ClassifierExperiment.run(): 3 short epochs on synthetic batches (reference-faithful mode: features + frozen BERT).
+    Epoch 1 runs at lr 0, afterwards the loss must fall; a checkpoint with the reference's keys is written."""
+    from mmgclip.config import compose
+    from mmgclip.dataset.synthetic import SyntheticLoader
+    from mmgclip.experiments.experiments_controller import create_experiment
+    from mmgclip.networks import bert
+    orig = bert.BertConfigLite.__init__
+
+    def small(self, **kw):
+        kw.setdefault("num_hidden_layers", 2)
+        kw.setdefault("vocab_size", 3000)
+        orig(self, **kw)
+    monkeypatch.setattr(bert.BertConfigLite, "__init__", small)
+    cfg_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmg-clip_amd", "configs")
+    cfg = compose(cfg_dir, "train_binary_class_clf", ["networks.text_encoder.random_init=true", "tokenizer=bert_clinical_seqlen=77",
+                                                      "scheduler=warmup1_epo15", "optimizer.config.learning_rate=3e-3"])
+    cfg.scheduler.config.epochs = 4
+    cfg.checkpoints.checkpoints_export_dir = str(tmp_path / "ckpt")
+    cfg.base.tensorboard_export_dir = str(tmp_path / "tb")
+    torch.manual_seed(0)
+    loader = SyntheticLoader(4, 32, seed=5, S=77, vocab_size=3000)
+    exp = create_experiment("classification")(config=cfg, train_dataloader=loader, valid_dataloader=SyntheticLoader(1, 32, seed=5, S=77, vocab_size=3000),
+                                              test_dataloader=None, tokenizer=None)
+    w0 = exp.model.image_projection_layer.layer.weight.detach().clone()
+    l1 = exp.train()
+    assert torch.equal(w0, exp.model.image_projection_layer.layer.weight.detach())      # epoch 1: lr = 0
+    exp.current_epoch = 1
+    l2 = exp.train()
+    exp.current_epoch = 2
+    l3 = exp.train()
+    assert l3 < l1 and not torch.equal(w0, exp.model.image_projection_layer.layer.weight.detach())
+    val = exp.validate()
+    assert np.isfinite(val)
+    exp.early_stopper(val, 2, exp.model, exp.optimizer, exp.ckp_path)
+    ckpt = torch.load(exp.ckp_path, weights_only=False)
+    assert sorted(ckpt) == sorted(["epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "best_score", "counter"])
+    assert "text_encoder.model.embeddings.word_embeddings.weight" in ckpt["model_state_dict"]
+    assert "image_projection_layer.layer.weight" in ckpt["model_state_dict"] and "logit_scale" not in ckpt["model_state_dict"]

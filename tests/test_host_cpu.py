@@ -1,0 +1,77 @@
+"""Host-side mirror classes that need no GPU: scheduler, early stopper, registries, config composer (vs golden vectors
+generated from the reference's own files)."""
+import json
+import os
+
+import pytest
+import torch
+
+
+def test_scheduler_class_matches_reference_golden(golden_dir):
+    from mmgclip.scheduler.warmup_cosine import LinearWarmupCosineAnnealingLR
+    ref = json.load(open(os.path.join(golden_dir, "g4_lr_schedule.json")))
+    for key, lrs in ref.items():
+        total, warm = key.split("_")
+        total, warm = int(total), (float(warm) if "." in warm else int(warm))
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=5e-5, weight_decay=1e-4)
+        sc = LinearWarmupCosineAnnealingLR(opt, total, warm)
+        mine = []
+        for _ in range(total):
+            mine.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sc.step()
+        assert mine == pytest.approx(lrs, rel=1e-12, abs=0)
+    with pytest.raises(AssertionError):
+        LinearWarmupCosineAnnealingLR(opt, 5, 5)
+
+
+def test_early_stopper_class_matches_reference_golden(golden_dir, tmp_path):
+    from mmgclip.callbacks.early_stopping import EarlyStopper
+    ref = json.load(open(os.path.join(golden_dir, "g7_early_stopper.json")))
+    model = torch.nn.Linear(2, 2)
+    opt = torch.optim.AdamW(model.parameters())
+    es = EarlyStopper(patience=5, trace_func=lambda *_: None)
+    path = str(tmp_path / "model.pth")
+    for epoch, v in enumerate(ref["trace"]):
+        es(v, epoch, model, opt, path)
+        st = ref["states"][epoch]
+        assert (es.counter, es.best_score, es.early_stop, es.val_loss_min) == (st["counter"], st["best_score"], st["early_stop"], st["val_loss_min"])
+    ckpt = torch.load(path, weights_only=False)
+    assert sorted(ckpt.keys()) == ref["checkpoint_keys"] and ckpt["epoch"] == ref["last_saved_epoch"]
+
+
+def test_registries_raise_like_the_reference():
+    from mmgclip.experiments.experiments_controller import create_experiment
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.network_controller import getNetworkClass
+    from mmgclip.networks.projection_controller import get_projection_head
+    assert create_loss("CLIPLoss").__name__ == "CLIPLoss"
+    assert get_projection_head("MultiLinearHead").__name__ == "MultiLinearHead"
+    assert getNetworkClass("BertEncoder").__name__ == "BertEncoder"
+    assert create_experiment("classification").__name__ == "ClassifierExperiment"
+    for fn, bad in ((create_loss, "X"), (get_projection_head, "ZeroProjection"), (getNetworkClass, "ConvNextTiny"), (create_experiment, "x")):
+        with pytest.raises(ValueError, match="Invalid network_name"):
+            fn(bad)
+
+
+def test_config_composer_reproduces_the_reference_surface():
+    from mmgclip.config import compose
+    cfg_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmg-clip_amd", "configs")
+    c = compose(cfg_dir, "train_binary_class_clf")
+    assert c.optimizer.config.learning_rate == 5e-5 and c.optimizer.config.weight_decay == 1e-4
+    assert c.scheduler.name == "cosine" and c.scheduler.config.epochs == 30 and c.scheduler.config.warmup_epochs == 0.1
+    assert c.networks.image_encoder.name == "ConvNextTiny" and c.networks.logit_temperature == 0.07
+    assert c.networks.dropout.config.dropout == 0.5 and c.dataset.percentage.config.percentage == 1
+    assert c.projection.config.projection_name == "LinearProjectionLayer" and c.tokenizer.config.sequence_length == 256
+    assert c.experiments.config.metrics == ["BenignMalignantDatasetLabels"]          # ${dataset.config.enums_class}
+    assert c.checkpoints.checkpoints_export_dir.startswith("outputs/") and c.checkpoints.checkpoints_export_dir.endswith("/checkpoints")
+    r = compose(cfg_dir, "train_exam_reports_clf", ["loss=mmgclip", "optimizer.config.learning_rate=1e-3"])
+    assert r.projection.config.output_projection_dimension == [768, 512] and r.loss.config.loss_name == "MMGCLIPLoss"
+    assert r.base.features_export_dir == "outputs/dataset/reports_studies/4_avg" and r.optimizer.config.learning_rate == 1e-3
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from mmgclip import head
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        head.L2Normalize.apply(torch.randn(4, 64))
