@@ -114,10 +114,11 @@ int mmg_colsum_bf16(const void* A, int lda, int M, int N, float* out, mmg_stream
  * (mmgclip/networks/encoder.py:53,156) and of MLPProjectionHead (mmgclip/networks/projection.py:100). */
 int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
                       float* mean, float* rstd, int M, int C, int patch, int H, int W, mmg_stream_t stream);
-/* dx (bf16) and dgamma/dbeta (fp32, ACCUMULATED; both NULL to skip) given dy in the layout the forward wrote. */
+/* dx (bf16) and dgamma/dbeta (fp32, ACCUMULATED; both NULL to skip) given dy in the layout the forward wrote;
+ * add (bf16 [M,C], nullable) is added to dx: the residual-path gradient of pre-LN transformer blocks. */
 int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
                       const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta, int M, int C, int patch,
-                      int H, int W, mmg_stream_t stream);
+                      int H, int W, const void* add, int ldadd, mmg_stream_t stream);
 
 /* y = GELU(x) elementwise, bf16, n % 8 == 0 (rebuilds the FFN activation in the backward pass). */
 int mmg_gelu_fwd_bf16(const void* x, void* y, long long n, mmg_stream_t stream);
@@ -195,6 +196,16 @@ int mmg_bert_embed_bwd(const void* g, const long long* ids, const long long* typ
 int mmg_eos_pool_fwd(const void* hidden, const long long* mask, float* out, int* idx_out, int B, int S, int H,
                      mmg_stream_t stream);
 int mmg_eos_pool_bwd(const float* dout, const int* idx, void* dhidden, int B, int S, int H, mmg_stream_t stream);
+
+/* ViT token assembly (torchvision VisionTransformer: class token + patch tokens + encoder.pos_embedding):
+ * out[b,0,:] = cls + pos[0]; out[b,1+p,:] = tok[b*Np+p,:] + pos[1+p]; S = Np + 1; all bf16. */
+int mmg_vit_assemble_fwd(const void* tok, const void* cls, const void* pos, void* out, int B, int S, int H,
+                         mmg_stream_t stream);
+/* dtok (bf16) = g rows 1..; dpos[S,H] += sum_b g; dcls[H] += sum_b g[b,0,:]  (fp32, accumulated) */
+int mmg_vit_assemble_bwd(const void* g, void* dtok, float* dpos, float* dcls, int B, int S, int H, mmg_stream_t stream);
+/* out[b,:] (fp32) = hidden[b*S + idx[b], :] — pooling at explicit token indices (class token: idx = 0);
+ * its backward is mmg_eos_pool_bwd. */
+int mmg_gather_rows_fwd(const void* hidden, const int* idx, float* out, int B, int S, int H, mmg_stream_t stream);
 
 #ifdef __cplusplus
 }

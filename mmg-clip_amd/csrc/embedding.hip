@@ -146,3 +146,74 @@ MMG_API int mmg_eos_pool_bwd(const float* dout, const int* idx, void* dhidden, i
     MMG_LAUNCH_CHECK("mmg_eos_pool_bwd");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ViT token assembly: X[b, 0, :] = cls + pos[0], X[b, 1+p, :] = tok[b*Np + p, :] + pos[1+p]   (bf16 in/out, fp32 add)
+// torchvision VisionTransformer._process_input + class_token concat + encoder.pos_embedding add.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restrict__ tok, const bf16_t* __restrict__ cls,
+                                                           const bf16_t* __restrict__ pos, bf16_t* __restrict__ out, int B,
+                                                           int S, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = H / 8, Np = S - 1;
+    for (int m = blockIdx.x * 4 + wave; m < B * S; m += gridDim.x * 4) {
+        const int b = m / S, s = m - b * S;
+        const bf16_t* src = s == 0 ? cls : tok + ((size_t)b * Np + (s - 1)) * H;
+        for (int c = lane; c < nch; c += 64) {
+            float a[8], p[8];
+            unpack8e(*reinterpret_cast<const uint4*>(src + c * 8), a);
+            unpack8e(*reinterpret_cast<const uint4*>(pos + (size_t)s * H + c * 8), p);
+            uint4 o;
+            o.x = pack2bf(a[0] + p[0], a[1] + p[1]); o.y = pack2bf(a[2] + p[2], a[3] + p[3]);
+            o.z = pack2bf(a[4] + p[4], a[5] + p[5]); o.w = pack2bf(a[6] + p[6], a[7] + p[7]);
+            *reinterpret_cast<uint4*>(out + (size_t)m * H + c * 8) = o;
+        }
+    }
+}
+MMG_API int mmg_vit_assemble_fwd(const void* tok, const void* cls, const void* pos, void* out, int B, int S, int H,
+                                 hipStream_t stream) {
+    MMG_CHECK_ARG(tok && cls && pos && out && B > 0 && S > 1 && H % 8 == 0, "mmg_vit_assemble_fwd: bad argument");
+    int blocks = cdiv(B * S, 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)tok, (const bf16_t*)cls,
+                       (const bf16_t*)pos, (bf16_t*)out, B, S, H);
+    MMG_LAUNCH_CHECK("mmg_vit_assemble_fwd");
+    return 0;
+}
+// backward: dtok[b*Np+p,:] = g[b,1+p,:] (bf16 copy) ; dpos[s,:] += sum_b g[b,s,:] ; dcls[:] += sum_b g[b,0,:]
+__global__ __launch_bounds__(256) void vit_assemble_bwd_kernel(const bf16_t* __restrict__ g, bf16_t* __restrict__ dtok,
+                                                               float* __restrict__ dpos, float* __restrict__ dcls, int B, int S,
+                                                               int H) {
+    const int s = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= H) return;
+    const int Np = S - 1;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const bf16_t v = g[((size_t)b * S + s) * H + c];
+        acc += bf2f(v);
+        if (s > 0) dtok[((size_t)b * Np + (s - 1)) * H + c] = v;
+    }
+    dpos[(size_t)s * H + c] += acc;
+    if (s == 0) dcls[c] += acc;
+}
+MMG_API int mmg_vit_assemble_bwd(const void* g, void* dtok, float* dpos, float* dcls, int B, int S, int H,
+                                 hipStream_t stream) {
+    MMG_CHECK_ARG(g && dtok && dpos && dcls && B > 0 && S > 1 && H > 0, "mmg_vit_assemble_bwd: bad argument");
+    hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3(S, cdiv(H, 256)), dim3(256), 0, stream, (const bf16_t*)g, (bf16_t*)dtok,
+                       dpos, dcls, B, S, H);
+    MMG_LAUNCH_CHECK("mmg_vit_assemble_bwd");
+    return 0;
+}
+// out[b,:] (fp32) = hidden[b*S + idx[b], :]  (row gather with explicit indices; ViT class-token pooling uses idx = 0)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ hidden, const int* __restrict__ idx,
+                                                          float* __restrict__ out, int S, int H) {
+    const int b = blockIdx.x;
+    const int i = idx[b];
+    for (int c = threadIdx.x; c < H; c += 256) out[(size_t)b * H + c] = bf2f(hidden[((size_t)b * S + i) * H + c]);
+}
+MMG_API int mmg_gather_rows_fwd(const void* hidden, const int* idx, float* out, int B, int S, int H, hipStream_t stream) {
+    MMG_CHECK_ARG(hidden && idx && out && B > 0 && S > 0 && H > 0, "mmg_gather_rows_fwd: bad argument");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, stream, (const bf16_t*)hidden, idx, out, S, H);
+    MMG_LAUNCH_CHECK("mmg_gather_rows_fwd");
+    return 0;
+}

@@ -28,6 +28,7 @@ struct LNArgs {
     const bf16_t* dy; int lddy;
     bf16_t* dx; int lddx;
     float* dgamma; float* dbeta;
+    const bf16_t* add; int ldadd;    // optional residual-path gradient added to dx (pre-LN transformer blocks)
 };
 
 __device__ __forceinline__ size_t ln_out_offset(const LNArgs& a, int m, int ld) {
@@ -153,6 +154,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LNArgs a) {
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rs * (g[k][e] - s1 - xh[k][e] * s2);
+                if (a.add) {
+                    float r[8];
+                    unpack8(*reinterpret_cast<const uint4*>(a.add + (size_t)m * a.ldadd + c * 8), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
                 *reinterpret_cast<uint4*>(a.dx + (size_t)m * a.lddx + c * 8) = pack8(o);
             }
         }
@@ -227,7 +234,7 @@ MMG_API int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const 
 
 MMG_API int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
                               const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta, int M, int C,
-                              int patch, int H, int W, hipStream_t stream) {
+                              int patch, int H, int W, const void* add, int ldadd, hipStream_t stream) {
     if (ln_check("mmg_layernorm_bwd", M, C, patch, H, W)) return 1;
     MMG_CHECK_ARG(dy && x && mean && rstd && gamma && dx && ((dgamma == nullptr) == (dbeta == nullptr)) &&
                       ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldx >= C && lddx >= C,
@@ -236,6 +243,8 @@ MMG_API int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, 
     a.x = (const bf16_t*)x; a.ldx = ldx; a.gamma = gamma; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd);
     a.M = M; a.C = C; a.patch = patch; a.H = H; a.W = W;
     a.dy = (const bf16_t*)dy; a.lddy = lddy; a.dx = (bf16_t*)dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.add = (const bf16_t*)add; a.ldadd = ldadd;
+    MMG_CHECK_ARG(!add || (ldadd >= C && ldadd % 8 == 0), "mmg_layernorm_bwd: bad ldadd=%d", ldadd);
     if (launch_ln<true>(a, stream)) return 1;
     MMG_LAUNCH_CHECK("mmg_layernorm_bwd");
     return 0;

@@ -26,12 +26,12 @@ def layernorm_fwd(x, gamma, beta, eps, patch_hw=None, want_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, patch_hw=None, out=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, patch_hw=None, out=None, add=None):
     M, C = x.shape
     dx = out if out is not None else torch.empty(M, C, device=x.device, dtype=BF16)
     patch, H, W = (0, 0, 0) if patch_hw is None else (1, patch_hw[0], patch_hw[1])
     call("mmg_layernorm_bwd", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
-         dx.stride(0), ptr(dgamma), ptr(dbeta), M, C, patch, H, W, stream())
+         dx.stride(0), ptr(dgamma), ptr(dbeta), M, C, patch, H, W, ptr(add), add.stride(0) if add is not None else 0, stream())
     return dx
 
 

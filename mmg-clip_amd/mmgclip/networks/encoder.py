@@ -18,6 +18,7 @@ import torch.nn as nn
 from ..utils.logger import logger
 from .bert import BertConfigLite, BertTower
 from .convnext import ConvNextTower
+from .vit import ViTTower
 
 PROJECTION_HEAD_DIM = 512
 
@@ -88,6 +89,23 @@ class ConvNextTinyEncoder(_ConvNextEncoder):
 
 class ConvNextBaseEncoder(_ConvNextEncoder):
     VARIANT = "base"
+
+
+class ViTB16Encoder(ViTTower):
+    """ViT-B/16 on raw pixels (BASELINE config C4; torchvision `vit_b_16` state-dict layout, class-token pooling)."""
+
+    def __init__(self, pretrained=None, image_features_dimension=None, in_chans=1, scale16=True, micro_batch=256, freeze=False,
+                 image_size=224, layers=12):
+        super().__init__(image_size=image_size, in_chans=in_chans, layers=layers, scale16=scale16, micro_batch=micro_batch)
+        if isinstance(pretrained, str) and os.path.isfile(pretrained):
+            sd = _load_state_file(pretrained)
+            self.model.load_state_dict({k: v for k, v in sd.items() if not k.startswith("heads.")}, strict=True)
+        if image_features_dimension is not None and image_features_dimension != self.model_output_dimension:
+            raise ValueError(f"ViTB16Encoder produces {self.model_output_dimension} features, config asks for {image_features_dimension}")
+        if freeze:
+            for p in self.parameters():
+                p.requires_grad = False
+        logger.info("Initializing 'ViTB16Encoder' as the image encoder.")
 
 
 class BertEncoder(BertTower):

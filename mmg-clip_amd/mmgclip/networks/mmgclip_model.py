@@ -19,7 +19,7 @@ from .bert import EosPool
 from .network_controller import getNetworkClass
 from .projection_controller import get_projection_head
 
-PIXEL_ENCODERS = ("ConvNextTinyEncoder", "ConvNextBaseEncoder")
+PIXEL_ENCODERS = ("ConvNextTinyEncoder", "ConvNextBaseEncoder", "ViTB16Encoder")
 
 
 def _get(cfg, path, default=None):
@@ -50,7 +50,8 @@ class MMGCLIP(nn.Module):
             self.image_encoder = getNetworkClass(enc_name)(
                 pretrained=_get(ie, "pretrained_path"), image_features_dimension=ie.image_features_dimension,
                 in_chans=_get(ie, "in_chans", 1), scale16=_get(ie, "scale16", True), micro_batch=_get(ie, "micro_batch", 64),
-                freeze=_get(ie, "freeze", False)).to(self.device)
+                freeze=_get(ie, "freeze", False),
+                **({"image_size": _get(ie, "image_size", 224)} if enc_name == "ViTB16Encoder" else {})).to(self.device)
             logger.info(f"Using {self.image_encoder.__class__.__name__}")
 
         te = self.config.networks.text_encoder

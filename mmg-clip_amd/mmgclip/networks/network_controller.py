@@ -1,4 +1,4 @@
-from .encoder import (BertEncoder, ConvNextBaseEncoder, ConvNextTinyEncoder, ResNet50Encoder)  # noqa: F401
+from .encoder import (BertEncoder, ConvNextBaseEncoder, ConvNextTinyEncoder, ResNet50Encoder, ViTB16Encoder)  # noqa: F401
 
 
 def getNetworkClass(network_name):

@@ -80,3 +80,32 @@ def bert_forward(sd, ids, attention_mask=None, token_type_ids=None, heads=12, ep
         x = F.layer_norm(f + a, (H,), g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"), eps)
         i += 1
     return x
+
+
+def vit_forward(sd, images, heads=12, patch=16, scale16=True, prefix=""):
+    """torchvision VisionTransformer (vit_b_16 layout) up to the class token after encoder.ln, fp32.  Not in the reference
+    (BASELINE config C4); pinned only by the published torchvision definition: conv_proj patches -> [cls; tokens] +
+    pos_embedding -> N x {x + MHA(ln_1(x)); x + MLP(ln_2(x))} -> encoder.ln -> x[:, 0]."""
+    g = lambda k: sd[prefix + k]                                           # noqa: E731
+    x = images
+    if scale16:
+        x = (65535.0 * x - 32767.5) / 32767.5
+    x = F.conv2d(x, g("conv_proj.weight"), g("conv_proj.bias"), stride=patch)
+    B, H = x.shape[0], x.shape[1]
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([g("class_token").expand(B, -1, -1), x], dim=1) + g("encoder.pos_embedding")
+    S = x.shape[1]
+    i = 0
+    while prefix + f"encoder.layers.encoder_layer_{i}.ln_1.weight" in sd:
+        p = f"encoder.layers.encoder_layer_{i}."
+        y = F.layer_norm(x, (H,), g(p + "ln_1.weight"), g(p + "ln_1.bias"), 1e-6)
+        qkv = F.linear(y, g(p + "self_attention.in_proj_weight"), g(p + "self_attention.in_proj_bias"))
+        q, k, v = (t.view(B, S, heads, H // heads).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+        a = ((q @ k.transpose(-1, -2)) / (H // heads) ** 0.5).softmax(-1) @ v
+        a = a.permute(0, 2, 1, 3).reshape(B, S, H)
+        x = x + F.linear(a, g(p + "self_attention.out_proj.weight"), g(p + "self_attention.out_proj.bias"))
+        z = F.layer_norm(x, (H,), g(p + "ln_2.weight"), g(p + "ln_2.bias"), 1e-6)
+        x = x + F.linear(F.gelu(F.linear(z, g(p + "mlp.0.weight"), g(p + "mlp.0.bias"))), g(p + "mlp.3.weight"), g(p + "mlp.3.bias"))
+        i += 1
+    x = F.layer_norm(x, (H,), g("encoder.ln.weight"), g("encoder.ln.bias"), 1e-6)
+    return x[:, 0]

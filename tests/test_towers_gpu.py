@@ -121,3 +121,33 @@ def test_bert_encoder_api_and_eos_pool(dev):
     assert r < 3e-2 and c > 0.999
     with pytest.raises(OSError):
         BertEncoder(pretrained="emilyalsentzer/Bio_ClinicalBERT")
+
+
+def test_vit_tower_forward_backward(dev):
+    from mmgclip.networks.encoder import ViTB16Encoder
+    torch.manual_seed(0)
+    tower = ViTB16Encoder(image_size=96, layers=3, micro_batch=2)          # S = 37 tokens
+    _randomize(tower, 8)
+    with torch.no_grad():
+        tower.model.class_token.normal_(std=0.5)
+    sd = {k[len("model."):]: v.clone() for k, v in tower.state_dict().items()}
+    img = torch.rand(3, 1, 96, 96, generator=torch.Generator().manual_seed(9))
+    wgt = torch.randn(3, 768, generator=torch.Generator().manual_seed(10))
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = E.vit_forward(osd, img)
+    (ref * wgt).sum().backward()
+    tower = tower.to(dev)
+    feat = tower(img.to(dev))
+    r, c = _rel(feat, ref)
+    assert r < 3e-2 and c > 0.999, (r, c)
+    (feat * wgt.to(dev)).sum().backward()
+    bad = {}
+    for name, p in tower.model.named_parameters():
+        if name.endswith("in_proj_bias"):
+            continue        # its key third has an exactly-zero gradient (softmax shift invariance): noise only
+        r, c = _rel(p.grad, osd[name].grad)
+        if not (c > 0.99 and r < 0.12):
+            bad[name] = (r, c)
+    assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
+    with pytest.raises(NotImplementedError):
+        ViTB16Encoder(image_size=1024)
