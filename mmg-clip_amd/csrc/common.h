@@ -88,6 +88,16 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return fmaf(x, pdf, cdf);
 }
 
+// 16-byte store that bypasses L2 allocation when `nt` (streaming outputs larger than the Infinity Cache)
+__device__ __forceinline__ void store16_stream(void* dst, const uint4 v, bool nt) {
+    if (nt) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(dst));
+    } else {
+        *reinterpret_cast<uint4*>(dst) = v;
+    }
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // gfx950 has 160 KiB of LDS per CU; anything above 64 KiB of dynamic LDS must be opted into.

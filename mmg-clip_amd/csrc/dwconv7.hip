@@ -48,7 +48,7 @@ __device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ x, unsigned*
 template <bool FLIP>
 __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const bf16_t* __restrict__ add,
-                                                         bf16_t* __restrict__ y, int H, int W, int C, int tiles_w) {
+                                                         bf16_t* __restrict__ y, int H, int W, int C, int tiles_w, int nt) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
     unsigned* tile = smem_u;                                             // [DW_ROWS][DW_ROWD] dwords (bf16 pairs)
     float* ws = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD);    // [49][32]
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restric
                 const int gw = w0 + strip * 8 + p;
                 if (gw < W) {
                     const size_t off = (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp;
-                    *reinterpret_cast<unsigned*>(y + off) = pack2bf(a0[p] + bf2f_lo(addv[p]), a1[p] + bf2f_hi(addv[p]));
+                    const unsigned o = pack2bf(a0[p] + bf2f_lo(addv[p]), a1[p] + bf2f_hi(addv[p]));
+                    if (nt) __builtin_nontemporal_store(o, reinterpret_cast<unsigned*>(y + off));
+                    else *reinterpret_cast<unsigned*>(y + off) = o;
                 }
             }
         }
@@ -222,14 +224,15 @@ MMG_API int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, c
     const int tiles_w = cdiv(W, DW_TW), tiles_h = cdiv(H, DW_TH);
     const size_t shm = (size_t)DW_ROWS * DW_ROWD * 4 + 49 * DW_CB * 4;
     const dim3 grid(tiles_w * tiles_h, C / DW_CB, n);
+    const int nt = (size_t)n * H * W * C * 2 >= ((size_t)256 << 20);
     if (flip) {
         mmg_allow_lds(dwconv7_kernel<true>, shm);
         hipLaunchKernelGGL(dwconv7_kernel<true>, grid, dim3(256), shm, stream, (const bf16_t*)x, w, bias, (const bf16_t*)add,
-                           (bf16_t*)y, H, W, C, tiles_w);
+                           (bf16_t*)y, H, W, C, tiles_w, nt);
     } else {
         mmg_allow_lds(dwconv7_kernel<false>, shm);
         hipLaunchKernelGGL(dwconv7_kernel<false>, grid, dim3(256), shm, stream, (const bf16_t*)x, w, bias, (const bf16_t*)add,
-                           (bf16_t*)y, H, W, C, tiles_w);
+                           (bf16_t*)y, H, W, C, tiles_w, nt);
     }
     MMG_LAUNCH_CHECK("mmg_dwconv7_nhwc");
     return 0;

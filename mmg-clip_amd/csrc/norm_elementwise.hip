@@ -29,6 +29,7 @@ struct LNArgs {
     bf16_t* dx; int lddx;
     float* dgamma; float* dbeta;
     const bf16_t* add; int ldadd;    // optional residual-path gradient added to dx (pre-LN transformer blocks)
+    int nt;                          // stream the output past L2 (tensor larger than the Infinity Cache)
 };
 
 __device__ __forceinline__ size_t ln_out_offset(const LNArgs& a, int m, int ld) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const LNArgs a) {
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mu) * rs * a.gamma[c * 8 + e] + a.beta[c * 8 + e];
-                *reinterpret_cast<uint4*>(a.y + obase + c * 8) = pack8(o);
+                store16_stream(a.y + obase + c * 8, pack8(o), a.nt);
             }
         }
         if (gl == 0) {
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LNArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += r[e];
                 }
-                *reinterpret_cast<uint4*>(a.dx + (size_t)m * a.lddx + c * 8) = pack8(o);
+                store16_stream(a.dx + (size_t)m * a.lddx + c * 8, pack8(o), a.nt);
             }
         }
     }
@@ -227,6 +228,7 @@ MMG_API int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const 
     LNArgs a = {};
     a.x = (const bf16_t*)x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps; a.y = (bf16_t*)y; a.ldy = ldy;
     a.mean = mean; a.rstd = rstd; a.M = M; a.C = C; a.patch = patch; a.H = H; a.W = W;
+    a.nt = (size_t)M * C * 2 >= ((size_t)256 << 20);
     if (launch_ln<false>(a, stream)) return 1;
     MMG_LAUNCH_CHECK("mmg_layernorm_fwd");
     return 0;
@@ -244,6 +246,7 @@ MMG_API int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, 
     a.M = M; a.C = C; a.patch = patch; a.H = H; a.W = W;
     a.dy = (const bf16_t*)dy; a.lddy = lddy; a.dx = (bf16_t*)dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta;
     a.add = (const bf16_t*)add; a.ldadd = ldadd;
+    a.nt = (size_t)M * C * 2 >= ((size_t)256 << 20);
     MMG_CHECK_ARG(!add || (ldadd >= C && ldadd % 8 == 0), "mmg_layernorm_bwd: bad ldadd=%d", ldadd);
     if (launch_ln<true>(a, stream)) return 1;
     MMG_LAUNCH_CHECK("mmg_layernorm_bwd");
