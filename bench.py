@@ -32,6 +32,7 @@ import torch.distributed as dist              # noqa: E402
 
 GFLOP_PER_PAIR = {  # fwd+bwd, 2 FLOP/MAC, train = 3 x forward
     ("tiny", 1024, 77): 557.4 + 39.9, ("tiny", 224, 77): 26.7 + 39.9, ("base", 1024, 77): 1923.6 + 39.9,
+    ("vit_b16", 1024, 77): 3949.0 + 39.9, ("vit_b16", 224, 77): 105.4 + 39.9,
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
@@ -42,7 +43,8 @@ def build(args, comm):
     from mmgclip.networks.mmgclip_model import MMGCLIP
     from mmgclip.optim import FusedAdamW
     from mmgclip.utils.global_utils import seeding
-    net = "clip_convnexttiny_bert_pixels" if args.variant == "tiny" else "clip_convnextbase_bert_pixels"
+    net = {"tiny": "clip_convnexttiny_bert_pixels", "base": "clip_convnextbase_bert_pixels",
+           "vit_b16": "clip_vitb16_bert_pixels"}[args.variant]
     cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf", [
         f"networks={net}", f"tokenizer=bert_clinical_seqlen={args.seq_len}", "networks/dropout=dropout0",
         f"networks.image_encoder.micro_batch={args.micro_batch}", f"networks.image_encoder.image_size={args.image_size}",
@@ -133,7 +135,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=1024)
     ap.add_argument("--seq-len", type=int, default=77)
     ap.add_argument("--micro-batch", type=int, default=64)
-    ap.add_argument("--variant", default="tiny", choices=["tiny", "base"])
+    ap.add_argument("--variant", default="tiny", choices=["tiny", "base", "vit_b16"],
+                    help="image tower: ConvNeXt-T (headline C2), ConvNeXt-B (C5 shape, bf16), ViT-B/16 (C4 shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -216,7 +219,8 @@ def main():
         "metric": "image-text pairs/sec (global batch)", "value": round(value, 2), "unit": "image-text pairs/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"C2: train_binary_class_clf, ConvNeXt-{args.variant} {args.image_size}x{args.image_size}x1 + BERT-base "
+        "config": {"workload": f"{'C2' if args.variant == 'tiny' else 'C4-shape' if args.variant == 'vit_b16' else 'C5-shape'}: train_binary_class_clf, "
+                               f"{'ViT-B/16' if args.variant == 'vit_b16' else 'ConvNeXt-' + args.variant} {args.image_size}x{args.image_size}x1 + BERT-base "
                                f"S={args.seq_len}, LinearProjection 768->512, CLIPLoss, AdamW, all parameters trained",
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "micro_batch": args.micro_batch,
                    "parallelism": f"dp{world}", "loss_scope": "global (all-gather)" if world > 1 else "local",

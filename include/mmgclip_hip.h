@@ -183,6 +183,15 @@ int mmg_attention_bwd(const void* qkv, int ld, const long long* mask, const void
                       const void* dctx, int lddc, void* dqkv, int lddq, int B, int S, int heads, int Hd, float scale,
                       mmg_stream_t stream);
 
+/* Flash-style tiled attention for sequences of any length (ViT-B/16 on 1024x1024: S = 4097; BERT training at S > 256):
+ * same layout and semantics as mmg_attention_fwd/bwd, K/V (or Q/dO) streamed through LDS in 64-row tiles, online
+ * softmax, no S x S tensor.  delta_ws: caller-provided fp32 [B*heads*S] scratch. */
+int mmg_attention_long_fwd(const void* qkv, int ld, const long long* mask, void* ctx, int ldc, float* lse, int B, int S,
+                           int heads, int Hd, float scale, mmg_stream_t stream);
+int mmg_attention_long_bwd(const void* qkv, int ld, const long long* mask, const void* ctx, int ldc, const float* lse,
+                           const void* dctx, int lddc, void* dqkv, int lddq, float* delta_ws, int B, int S, int heads,
+                           int Hd, float scale, mmg_stream_t stream);
+
 /* out[m,:] = word[ids[m]] + pos[m % S] + type[type_ids[m]] (bf16 tables [V|P|T, H]); HF BertEmbeddings before its
  * LayerNorm (mmgclip/networks/encoder.py:156). */
 int mmg_bert_embed_fwd(const long long* ids, const long long* type_ids, const void* word, const void* pos,

@@ -347,3 +347,291 @@ MMG_API int mmg_attention_bwd(const void* qkv, int ld, const long long* mask, co
     MMG_LAUNCH_CHECK("mmg_attention_bwd");
     return 0;
 }
+
+// =============================================================================================
+// Long sequences (ViT-B/16 at 1024x1024: S = 4097; BERT training at S > 256): flash-style tiling.
+// Same fragments and LDS images as above, but K/V (forward, dQ) or Q/dO (dK,dV) stream through LDS in 64-row tiles
+// and the softmax is computed online; nothing of size S x S exists anywhere.  One workgroup = (sequence, head,
+// 64-row block), 4 waves x 16 rows.  The backward is two kernels (dQ by query block, dK/dV by key block), so every
+// output row has one writer (no atomics, bitwise reproducible).
+// =============================================================================================
+#define ATT_TILE 64
+
+__device__ __forceinline__ void att_stage_tile(const bf16_t* __restrict__ src, int ld, char* img, int row0, int S) {
+    for (int idx = threadIdx.x; idx < ATT_TILE * 8; idx += 256) {
+        const int r = idx >> 3, c = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row0 + r < S) v = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8);
+        *reinterpret_cast<uint4*>(img + att_off(r, c)) = v;
+    }
+}
+
+// row fragment straight from global memory: lane (li, g) gets row (r0 + li, clamped)[32*ks + 8*g .. +7]
+__device__ __forceinline__ bf16x8 att_global_frag(const bf16_t* __restrict__ base, int ld, int r0, int ks, int lane, int S) {
+    const int r = min(r0 + (lane & 15), S - 1);
+    return *reinterpret_cast<const bf16x8*>(base + (size_t)r * ld + ks * 32 + (lane >> 4) * 8);
+}
+
+__global__ __launch_bounds__(256) void attn_long_fwd_kernel(const AttArgs a) {
+    __shared__ __attribute__((aligned(16))) char Ks[ATT_TILE * 128];
+    __shared__ __attribute__((aligned(16))) char Vs[ATT_TILE * 128];
+    __shared__ __attribute__((aligned(16))) float madd[ATT_TILE];
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
+    const int q0 = blockIdx.y * ATT_TILE + wave * 16;
+    const bf16x8 qf0 = att_global_frag(base, a.ld, q0, 0, lane, a.S), qf1 = att_global_frag(base, a.ld, q0, 1, lane, a.S);
+    float m = ATT_NEG, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = (a.S + ATT_TILE - 1) / ATT_TILE;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * ATT_TILE;
+        __syncthreads();
+        att_stage_tile(base + a.Hd, a.ld, Ks, k0, a.S);
+        att_stage_tile(base + 2 * a.Hd, a.ld, Vs, k0, a.S);
+        if (threadIdx.x < ATT_TILE) {
+            const int k = k0 + threadIdx.x;
+            madd[threadIdx.x] = (k < a.S && (!a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
+        }
+        __syncthreads();
+        f32x4 sc[4];
+        float tmax = ATT_NEG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, 0, lane), qf0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, 1, lane), qf1, acc, 0, 0, 0);
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(madd + t * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] = acc[r] * a.scale + mk[r];
+                tmax = fmaxf(tmax, acc[r]);
+            }
+            sc[t] = acc;
+        }
+        const float mn = fmaxf(m, group4_max(tmax));
+        const float alpha = __expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[t][r] = __expf(sc[t][r] - mn);
+                ps += sc[t][r];
+            }
+        l = l * alpha + ps;          // partial over this lane group's keys; groups are summed at the end
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bf16x8 pf = pack_frag(sc[2 * c], sc[2 * c + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Vs, c * 32, dt, lane), pf, o[dt], 0, 0, 0);
+        }
+    }
+    l = group4_sum(l);
+    const float inv = 1.0f / l;
+    if (q0 + li < a.S) {
+        bf16_t* dst = a.ctx + ((size_t)b * a.S + q0 + li) * a.ldc + h * ATT_D + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 v;
+            v.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+            v.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+            *reinterpret_cast<uint2*>(dst + dt * 16) = v;
+        }
+        if (g == 0 && a.lse) a.lse[((size_t)b * a.heads + h) * a.S + q0 + li] = m + __logf(l);
+    }
+}
+
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per (row, head))
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ ctx, int ldc, const bf16_t* __restrict__ dctx,
+                                                         int lddc, float* __restrict__ delta, int B, int S, int heads) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long total = (long)B * S * heads;
+    for (long idx = (long)blockIdx.x * 4 + wave; idx < total; idx += (long)gridDim.x * 4) {
+        const int h = (int)(idx % heads);
+        const long row = idx / heads;                 // b*S + q
+        const float v = bf2f(ctx[row * ldc + h * ATT_D + lane]) * bf2f(dctx[row * lddc + h * ATT_D + lane]);
+        const float s = wave_sum(v);
+        if (lane == 0) delta[((row / S) * heads + h) * S + (row % S)] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_long_dq_kernel(const AttArgs a, const float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) char Ks[ATT_TILE * 128];
+    __shared__ __attribute__((aligned(16))) char Vs[ATT_TILE * 128];
+    __shared__ __attribute__((aligned(16))) float madd[ATT_TILE];
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
+    const bf16_t* gbase = a.dctx + (size_t)b * a.S * a.lddc + h * ATT_D;
+    const int q0 = blockIdx.y * ATT_TILE + wave * 16;
+    const bf16x8 qf0 = att_global_frag(base, a.ld, q0, 0, lane, a.S), qf1 = att_global_frag(base, a.ld, q0, 1, lane, a.S);
+    const bf16x8 gf0 = att_global_frag(gbase, a.lddc, q0, 0, lane, a.S), gf1 = att_global_frag(gbase, a.lddc, q0, 1, lane, a.S);
+    const bool qok = q0 + li < a.S;
+    const size_t sidx = ((size_t)b * a.heads + h) * a.S + min(q0 + li, a.S - 1);
+    const float lq = qok ? a.lse[sidx] : 1.0e30f, dl = qok ? delta[sidx] : 0.f;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = (a.S + ATT_TILE - 1) / ATT_TILE;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * ATT_TILE;
+        __syncthreads();
+        att_stage_tile(base + a.Hd, a.ld, Ks, k0, a.S);
+        att_stage_tile(base + 2 * a.Hd, a.ld, Vs, k0, a.S);
+        if (threadIdx.x < ATT_TILE) {
+            const int k = k0 + threadIdx.x;
+            madd[threadIdx.x] = (k < a.S && (!a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
+        }
+        __syncthreads();
+        f32x4 ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, 0, lane), qf0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, 1, lane), qf1, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Vs, t * 16, 0, lane), gf0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Vs, t * 16, 1, lane), gf1, dp, 0, 0, 0);
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(madd + t * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[r] * a.scale + mk[r] - lq);
+                ds[t][r] = p * (dp[r] - dl) * a.scale;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bf16x8 dsf = pack_frag(ds[2 * c], ds[2 * c + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Ks, c * 32, dt, lane), dsf, dq[dt], 0, 0, 0);
+        }
+    }
+    if (qok) {
+        bf16_t* dst = a.dqkv + ((size_t)b * a.S + q0 + li) * a.lddq + h * ATT_D + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 v;
+            v.x = pack2bf(dq[dt][0], dq[dt][1]);
+            v.y = pack2bf(dq[dt][2], dq[dt][3]);
+            *reinterpret_cast<uint2*>(dst + dt * 16) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_long_dkv_kernel(const AttArgs a, const float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) char Qs[ATT_TILE * 128];
+    __shared__ __attribute__((aligned(16))) char Gs[ATT_TILE * 128];
+    __shared__ __attribute__((aligned(16))) float lses[ATT_TILE];
+    __shared__ __attribute__((aligned(16))) float dels[ATT_TILE];
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
+    const bf16_t* gbase = a.dctx + (size_t)b * a.S * a.lddc + h * ATT_D;
+    const int k0 = blockIdx.y * ATT_TILE + wave * 16;
+    const bf16x8 kf0 = att_global_frag(base + a.Hd, a.ld, k0, 0, lane, a.S), kf1 = att_global_frag(base + a.Hd, a.ld, k0, 1, lane, a.S);
+    const bf16x8 vf0 = att_global_frag(base + 2 * a.Hd, a.ld, k0, 0, lane, a.S), vf1 = att_global_frag(base + 2 * a.Hd, a.ld, k0, 1, lane, a.S);
+    const int key = k0 + li;
+    const float mk = (key < a.S && (!a.mask || a.mask[(size_t)b * a.S + key] != 0)) ? 0.f : ATT_NEG;
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int ntiles = (a.S + ATT_TILE - 1) / ATT_TILE;
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int q0 = qt * ATT_TILE;
+        __syncthreads();
+        att_stage_tile(base, a.ld, Qs, q0, a.S);
+        att_stage_tile(gbase, a.lddc, Gs, q0, a.S);
+        if (threadIdx.x < ATT_TILE) {
+            const int q = q0 + threadIdx.x;
+            const size_t si = ((size_t)b * a.heads + h) * a.S + min(q, a.S - 1);
+            lses[threadIdx.x] = q < a.S ? a.lse[si] : 1.0e30f;
+            dels[threadIdx.x] = q < a.S ? delta[si] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 pp[2], ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ql = c * 32 + t * 16;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Qs, ql, 0, lane), kf0, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Qs, ql, 1, lane), kf1, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Gs, ql, 0, lane), vf0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Gs, ql, 1, lane), vf1, dp, 0, 0, 0);
+                const f32x4 lq = *reinterpret_cast<const f32x4*>(lses + ql + 4 * g);
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(dels + ql + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(s[r] * a.scale + mk - lq[r]);
+                    pp[t][r] = p;
+                    ds[t][r] = p * (dp[r] - dl[r]) * a.scale;
+                }
+            }
+            const bf16x8 pf = pack_frag(pp[0], pp[1]), dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Gs, c * 32, dt, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Qs, c * 32, dt, lane), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (key < a.S) {
+        bf16_t* dst = a.dqkv + ((size_t)b * a.S + key) * a.lddq + h * ATT_D + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 v;
+            v.x = pack2bf(dk[dt][0], dk[dt][1]);
+            v.y = pack2bf(dk[dt][2], dk[dt][3]);
+            *reinterpret_cast<uint2*>(dst + a.Hd + dt * 16) = v;
+            v.x = pack2bf(dv[dt][0], dv[dt][1]);
+            v.y = pack2bf(dv[dt][2], dv[dt][3]);
+            *reinterpret_cast<uint2*>(dst + 2 * a.Hd + dt * 16) = v;
+        }
+    }
+}
+
+// Tiled (flash-style) attention for any S: same contract as mmg_attention_fwd.
+MMG_API int mmg_attention_long_fwd(const void* qkv, int ld, const long long* mask, void* ctx, int ldc, float* lse, int B, int S,
+                                   int heads, int Hd, float scale, hipStream_t stream) {
+    if (att_check("mmg_attention_long_fwd", B, S, heads, Hd, ld, 1 << 20)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && ldc >= Hd && ldc % 8 == 0 && (long)B * heads <= 0x7fffffffL, "mmg_attention_long_fwd: bad ctx");
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = lse;
+    a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    hipLaunchKernelGGL(attn_long_fwd_kernel, dim3(B * heads, cdiv(S, ATT_TILE)), dim3(256), 0, stream, a);
+    MMG_LAUNCH_CHECK("mmg_attention_long_fwd");
+    return 0;
+}
+
+// Backward for any S.  delta_ws: caller-provided fp32 workspace of B*heads*S elements (receives rowsum(dO*O)).
+MMG_API int mmg_attention_long_bwd(const void* qkv, int ld, const long long* mask, const void* ctx, int ldc, const float* lse,
+                                   const void* dctx, int lddc, void* dqkv, int lddq, float* delta_ws, int B, int S, int heads,
+                                   int Hd, float scale, hipStream_t stream) {
+    if (att_check("mmg_attention_long_bwd", B, S, heads, Hd, ld, 1 << 20)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta_ws && ldc >= Hd && lddc >= Hd && lddq >= 3 * Hd && ldc % 8 == 0 &&
+                      lddc % 8 == 0 && lddq % 8 == 0, "mmg_attention_long_bwd: bad pointer or leading dimension");
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = const_cast<float*>(lse);
+    a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    a.dctx = (const bf16_t*)dctx; a.lddc = lddc; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
+    long rows = (long)B * S * heads;
+    int blocks = (int)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)ctx, ldc, (const bf16_t*)dctx, lddc,
+                       delta_ws, B, S, heads);
+    const dim3 grid(B * heads, cdiv(S, ATT_TILE));
+    hipLaunchKernelGGL(attn_long_dq_kernel, grid, dim3(256), 0, stream, a, (const float*)delta_ws);
+    hipLaunchKernelGGL(attn_long_dkv_kernel, grid, dim3(256), 0, stream, a, (const float*)delta_ws);
+    MMG_LAUNCH_CHECK("mmg_attention_long_bwd");
+    return 0;
+}

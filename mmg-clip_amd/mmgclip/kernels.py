@@ -95,19 +95,26 @@ def dwconv7_wgrad(x, dy, dw49, dbias, n, H, W, C):
     call("mmg_dwconv7_wgrad", ptr(x), ptr(dy), ptr(dw49), ptr(dbias), n, H, W, C, stream())
 
 
-def attention_fwd(qkv, mask, B, S, heads, want_lse=True):
+def attention_fwd(qkv, mask, B, S, heads, want_lse=True, force_long=False):
+    """Whole-sequence-in-LDS kernel up to S = 512, flash-style tiled kernel beyond (or when force_long)."""
     Hd = heads * 64
     ctx = torch.empty(B * S, Hd, device=qkv.device, dtype=BF16)
     lse = torch.empty(B, heads, S, device=qkv.device, dtype=torch.float32) if want_lse else None
-    call("mmg_attention_fwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), Hd, ptr(lse), B, S, heads, Hd, 0.125, stream())
+    name = "mmg_attention_long_fwd" if (force_long or S > 512) else "mmg_attention_fwd"
+    call(name, ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), Hd, ptr(lse), B, S, heads, Hd, 0.125, stream())
     return ctx, lse
 
 
-def attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, out=None):
+def attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, out=None, force_long=False):
     Hd = heads * 64
     dqkv = out if out is not None else torch.empty(B * S, 3 * Hd, device=qkv.device, dtype=BF16)
-    call("mmg_attention_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),
-         dctx.stride(0), ptr(dqkv), dqkv.stride(0), B, S, heads, Hd, 0.125, stream())
+    if force_long or S > 256:
+        delta = torch.empty(B * heads * S, device=qkv.device, dtype=torch.float32)
+        call("mmg_attention_long_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),
+             dctx.stride(0), ptr(dqkv), dqkv.stride(0), ptr(delta), B, S, heads, Hd, 0.125, stream())
+    else:
+        call("mmg_attention_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),
+             dctx.stride(0), ptr(dqkv), dqkv.stride(0), B, S, heads, Hd, 0.125, stream())
     return dqkv
 
 

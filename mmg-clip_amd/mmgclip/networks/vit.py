@@ -7,8 +7,8 @@ ViT-B/16, 768 features).  Layout follows torchvision.models.VisionTransformer: `
 ln_2, mlp.{0,3}}`, `encoder.ln`; LayerNorm eps 1e-6, erf-GELU, no dropout.  The oracle is oracle/encoders_oracle.vit_forward.
 
 All layers reuse the BERT/ConvNeXt kernels: the 16x16/16 patch convolution is `mmg_patchify` + GEMM, attention is
-`mmg_attention_fwd/bwd` without a key mask.  The attention backward holds a whole sequence in LDS, so S = (H/16)(W/16)+1
-must be <= 256 (224x224 -> 197); the 1024x1024 case of C4 (S = 4097) needs a tiled long-sequence kernel (not built yet).
+`mmg_attention_fwd/bwd` without a key mask (whole sequence in LDS) up to S = 256 tokens (224x224 -> 197) and the
+flash-style tiled `mmg_attention_long_fwd/bwd` beyond (1024x1024 -> S = 4097, BASELINE config C4).
 """
 import torch
 import torch.nn as nn
@@ -62,9 +62,6 @@ class ViTTower(nn.Module):
         self.image_size, self.in_chans, self.hidden, self.layers, self.heads = image_size, in_chans, hidden, layers, heads
         self.mlp_dim, self.patch, self.scale16, self.micro_batch = mlp_dim, patch, scale16, micro_batch
         self.seq = (image_size // patch) ** 2 + 1
-        if self.seq > 256:
-            raise NotImplementedError(f"ViT sequence length {self.seq} > 256: the attention backward keeps a sequence in LDS; "
-                                      "the long-sequence (tiled) attention kernel for 1024x1024 inputs is not built yet")
         self.model = _tv_layout(image_size, in_chans, hidden, layers, mlp_dim, patch)
         self.model_output_dimension = hidden
         self.kp = (patch * patch * in_chans + 31) // 32 * 32

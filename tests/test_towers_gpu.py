@@ -149,5 +149,26 @@ def test_vit_tower_forward_backward(dev):
         if not (c > 0.99 and r < 0.12):
             bad[name] = (r, c)
     assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
-    with pytest.raises(NotImplementedError):
-        ViTB16Encoder(image_size=1024)
+
+
+def test_vit_tower_long_sequence_path(dev):
+    """S = (272/16)^2 + 1 = 290 > 256 tokens: the tiled attention kernels carry the forward and the backward."""
+    from mmgclip.networks.encoder import ViTB16Encoder
+    torch.manual_seed(0)
+    tower = ViTB16Encoder(image_size=272, layers=2, micro_batch=2)
+    _randomize(tower, 12)
+    sd = {k[len("model."):]: v.clone() for k, v in tower.state_dict().items()}
+    img = torch.rand(2, 1, 272, 272, generator=torch.Generator().manual_seed(13))
+    wgt = torch.randn(2, 768, generator=torch.Generator().manual_seed(14))
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = E.vit_forward(osd, img)
+    (ref * wgt).sum().backward()
+    tower = tower.to(dev)
+    feat = tower(img.to(dev))
+    r, c = _rel(feat, ref)
+    assert r < 3e-2 and c > 0.999, (r, c)
+    (feat * wgt.to(dev)).sum().backward()
+    for name in ("conv_proj.weight", "encoder.layers.encoder_layer_0.self_attention.in_proj_weight",
+                 "encoder.layers.encoder_layer_1.mlp.0.weight", "encoder.pos_embedding"):
+        r, c = _rel(tower.model.get_parameter(name).grad, osd[name].grad)
+        assert c > 0.99 and r < 0.12, (name, r, c)
