@@ -44,8 +44,42 @@ def synthetic_batch(n, S=77, image_size=None, in_chans=1, feature_dim=768, vocab
     batch["image_label"] = torch.randint(0, 2, (n, 1), generator=g)
     batch["image_id"] = [f"synthetic_{seed}_{i}" for i in range(n)]
     batch["image_description"] = ["synthetic"] * n
-    batch["prompt_labels"] = [{} for _ in range(n)]
+    shapes = torch.randint(0, 4, (n,), generator=g)
+    birads = torch.randint(-1, 7, (n,), generator=g)
+    batch["prompt_labels"] = [{"BenignMalignantDatasetLabels": int(batch["image_label"][i, 0]), "MassShapeLabels": int(shapes[i]),
+                               "BIRADS": "unknown" if int(birads[i]) < 0 else str(int(birads[i]))} for i in range(n)]
     return batch
+
+
+# label enums of the reference (mmgclip/prompts/enums.py:17-19,29-34) that the validation prompts are built from
+BENIGN_MALIGNANT = {"benign": 0, "malignant": 1}
+MASS_SHAPES = {"unknown": 0, "oval": 1, "round": 2, "irregular": 3}
+
+
+def validation_prompts(metrics):
+    """The prompt strings ClassifierExperiment.validate builds (ClassifierExperiment.py:147-163), keyed by metric."""
+    out = {}
+    if "BenignMalignantDatasetLabels" in metrics:
+        out["malig"] = ["Finding suggesting malignant."]
+    if "MassShapeLabels" in metrics:
+        out["shapes"] = [f"Mass shape is {name}." for name in MASS_SHAPES]
+    if "birads" in metrics:
+        out["birads"] = ["BIRADS unknown."] + [f"BIRADS score of {i}." for i in range(0, 7)]
+    return out
+
+
+def synthetic_prompt_tokens(strings, S, vocab_size=28996):
+    """Deterministic stand-in for the absent tokenizer vocabulary: ids hashed from the words of each prompt."""
+    import zlib
+    n = len(strings)
+    ids = torch.zeros(n, S, dtype=torch.long)
+    mask = torch.zeros(n, S, dtype=torch.long)
+    for i, text in enumerate(strings):
+        words = text.replace(".", " .").split()
+        toks = [101] + [1000 + zlib.crc32(w.lower().encode()) % (vocab_size - 1000) for w in words][:S - 2] + [102]
+        ids[i, :len(toks)] = torch.tensor(toks)
+        mask[i, :len(toks)] = 1
+    return TokenBatch(input_ids=ids, token_type_ids=torch.zeros(n, S, dtype=torch.long), attention_mask=mask)
 
 
 class SyntheticLoader:

@@ -3,8 +3,9 @@ mmgclip/experiments/ClassifierExperiment.py:34-344: build model / loss / AdamW /
 `run()`: for each epoch `train()` (zero_grad(set_to_none) -> model(batch) -> criterion(**outputs) -> backward ->
 optimizer.step(); scheduler stepped ONCE PER EPOCH, so epoch 1 runs at lr 0: SURVEY.md §0) and `validate()`.
 
-Scope: the train loop and the validation LOSS are reproduced; the prompt-AUROC metrics of
-`validate()` / `test()` (sklearn + re-encoding 1/4/8 prompts per batch) are listed as "next" and not built here.
+Scope: the train loop and `validate()` (loss + zero-shot prompt AUROC: 1 malignancy prompt, 4 mass
+shape prompts, 8 BI-RADS prompts; prompt embeddings cached once per call instead of re-encoded per batch) are reproduced;
+`test()` (the offline Evaluator with bootstrap CIs, confusion matrices and plots) is out of scope.
 Additive options: `distributed.global_loss`, `optimizer.config.fused` (FusedAdamW over the parameter arenas).
 """
 import os
@@ -99,32 +100,91 @@ class ClassifierExperiment:
         self.writer.add_scalar('loss/train', epoch_loss, self.current_epoch + 1)
         return epoch_loss
 
+    def _prompt_token_sets(self):
+        """{metric: tokens of its k prompts}: the tokenizer when the caller supplied one, else hashed stand-in ids."""
+        from ..dataset.synthetic import synthetic_prompt_tokens, validation_prompts
+        S = self.config.tokenizer.config.sequence_length
+        sets = {}
+        for name, strings in validation_prompts(self.config.experiments.config.metrics).items():
+            if self.tokenizer is not None:
+                sets[name] = self.tokenizer(strings, padding="max_length", truncation=True, return_tensors="pt", max_length=S)
+            else:
+                sets[name] = synthetic_prompt_tokens(strings, S, self.model.text_encoder.config.vocab_size)
+        return sets
+
+    @staticmethod
+    def _auc(y_true, y_score):
+        from sklearn import metrics
+        y_true = np.asarray(y_true)
+        if y_true.min() == y_true.max():
+            return float("nan")              # one class only in this split: AUROC undefined
+        fpr, tpr, _ = metrics.roc_curve(y_true, y_score)
+        return float(metrics.auc(fpr, tpr))
+
     def validate(self):
-        """Validation loss (the prompt-AUROC part of ClassifierExperiment.py:134-289 is out of scope, see module doc)."""
+        """Validation loss + zero-shot prompt AUROC (ClassifierExperiment.py:134-289): malignancy (1 prompt), mass shape
+        (4 prompts, one-vs-rest mean), BI-RADS (8 prompts, one-vs-rest mean).  Returns the reference's 5-tuple
+        (loss, auc_malig, auc_shapes, auc_birads, auc_mean), -1 for metrics that are not configured.
+
+        The reference re-encodes the same prompts through BERT for every batch (:192-229); here their embeddings are
+        computed ONCE per call and every batch only runs the [n,D] x [D,k] logit kernel."""
+        from .. import head
         self.model.eval()
-        loss_list = []
+        metric_names = self.config.experiments.config.metrics
+        loss_list, targets, preds = [], {}, {}
         with torch.no_grad():
+            prompt_emb = {}
+            for name, tokens in self._prompt_token_sets().items():
+                tf = self.model.encode_text({"text_tokens": tokens})
+                te = self.model.text_projection_layer(tf) if self.model.text_projection_layer is not None else tf
+                prompt_emb[name] = head.L2Normalize.apply(te).contiguous()
+                targets[name], preds[name] = [], []
             for batch in self.valid_dataloader:
                 outputs = self.model(batch, validation=True)
-                outputs.pop("text_embeddings2", None)
-                loss, _ = self.criterion(**outputs) if "text_embeddings2" not in self.criterion.forward.__code__.co_varnames \
-                    else create_loss("CLIPLoss")()(**outputs)
+                loss, _ = self.criterion(**{k: v for k, v in outputs.items() if k != "text_embeddings2"}) \
+                    if self.criterion.__class__.__name__ != "MMGCLIPLoss" else create_loss("CLIPLoss")()(**outputs)
                 loss_list.append(loss.item())
-        val_loss = float(np.mean(loss_list)) if loss_list else float("nan")
-        self.writer.add_scalar('loss/val', val_loss, self.current_epoch + 1)
-        return val_loss
+                labels = batch["prompt_labels"]
+                scale = outputs["logit_scale"].reshape(1).float().contiguous()
+                for name, te in prompt_emb.items():
+                    _, _, sims = head.rows_forward(outputs["image_embeddings"].contiguous(), te, scale, 0, True)   # [n,k]
+                    preds[name].append(sims.cpu().numpy())
+                    if name == "malig":
+                        targets[name].extend(int(l["BenignMalignantDatasetLabels"]) for l in labels)
+                    elif name == "shapes":
+                        targets[name].extend(int(l["MassShapeLabels"]) for l in labels)
+                    else:
+                        targets[name].extend(-1 if l["BIRADS"] == "unknown" else int(l["BIRADS"]) for l in labels)
+        epoch_loss = float(np.mean(loss_list)) if loss_list else float("nan")
+        self.writer.add_scalar('loss/val', epoch_loss, self.current_epoch + 1)
+        aucs = {}
+        for name in preds:
+            p = np.concatenate(preds[name], 0)
+            t = np.asarray(targets[name])
+            if name == "malig":
+                aucs[name] = self._auc(t, p[:, 0])
+            else:
+                off = 1 if name == "birads" else 0        # BI-RADS prompt idx 0 is "unknown" (label -1)
+                aucs[name] = float(np.nanmean([self._auc(t == (i - off), p[:, i]) for i in range(p.shape[1])]))
+            self.writer.add_scalar(f'auc/val/{name}', aucs[name], self.current_epoch + 1)
+        mean_auc = float(np.mean(list(aucs.values()))) if len(aucs) > 1 else -1
+        if len(aucs) > 1:
+            self.writer.add_scalar('auc/val/average', mean_auc, self.current_epoch + 1)
+        return (epoch_loss, aucs.get("malig", -1), aucs.get("shapes", -1), aucs.get("birads", -1),
+                mean_auc if len(metric_names) > 1 else -1)
 
     def run(self):
         self._time_start = time.time()
         for self.current_epoch in range(self.config.scheduler.config.epochs):
             t0 = time.time()
             train_loss = self.train()
-            val_loss = self.validate() if self.valid_dataloader is not None else train_loss
+            val = self.validate() if self.valid_dataloader is not None else (train_loss, -1, -1, -1, -1)
+            val_loss = val[0]
             mins, secs = epoch_time(t0, time.time())
             self.writer.add_scalar('lr', self.optimizer.param_groups[0]['lr'], self.current_epoch + 1)
             self.early_stopper(val_loss, self.current_epoch, self.model, self.optimizer, self.ckp_path)
             logger.info(f"Epoch: {self.current_epoch + 1:02} | Time: {mins}m {secs}s | train loss {train_loss:.4f} | "
-                        f"val loss {val_loss:.4f}")
+                        f"val loss {val_loss:.4f} | val AUC malig/shapes/birads/mean {val[1]:.3f}/{val[2]:.3f}/{val[3]:.3f}/{val[4]:.3f}")
             if self.early_stopper.early_stop:
                 logger.info("Early stopping")
                 break

@@ -94,9 +94,55 @@ def test_classifier_experiment_runs_like_the_reference_loop(dev, tmp_path, monke
     l3 = exp.train()
     assert l3 < l1 and not torch.equal(w0, exp.model.image_projection_layer.layer.weight.detach())
     val = exp.validate()
-    assert np.isfinite(val)
-    exp.early_stopper(val, 2, exp.model, exp.optimizer, exp.ckp_path)
+    assert len(val) == 5 and np.isfinite(val[0])                # (loss, auc_malig, auc_shapes, auc_birads, auc_mean)
+    assert 0.0 <= val[1] <= 1.0 and val[2] == -1 and val[3] == -1 and val[4] == -1    # binary config: malignancy only
+    exp.early_stopper(val[0], 2, exp.model, exp.optimizer, exp.ckp_path)
     ckpt = torch.load(exp.ckp_path, weights_only=False)
     assert sorted(ckpt) == sorted(["epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "best_score", "counter"])
     assert "text_encoder.model.embeddings.word_embeddings.weight" in ckpt["model_state_dict"]
     assert "image_projection_layer.layer.weight" in ckpt["model_state_dict"] and "logit_scale" not in ckpt["model_state_dict"]
+
+
+def test_validation_prompt_scores_match_oracle(dev, monkeypatch):
+    """Zero-shot prompt scoring of validate(): cached prompt embeddings + the [n,D]x[D,k] logit kernel equal the reference
+    arithmetic (logit_scale * image_embeddings @ prompt_embeddings.t(), ClassifierExperiment.py:192-229) on the oracle."""
+    from mmgclip import head
+    from mmgclip.config import compose
+    from mmgclip.dataset.synthetic import synthetic_batch, synthetic_prompt_tokens, validation_prompts
+    from mmgclip.networks import bert
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    from oracle import clip_oracle as O
+    from oracle import encoders_oracle as E
+    orig = bert.BertConfigLite.__init__
+
+    def small(self, **kw):
+        kw.setdefault("num_hidden_layers", 2)
+        kw.setdefault("vocab_size", 3000)
+        orig(self, **kw)
+    monkeypatch.setattr(bert.BertConfigLite, "__init__", small)
+    cfg_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmg-clip_amd", "configs")
+    cfg = compose(cfg_dir, "train_exam_reports_clf", ["networks.text_encoder.random_init=true", "tokenizer=bert_clinical_seqlen=77",
+                                                      "networks/dropout=dropout0"])
+    torch.manual_seed(0)
+    model = MMGCLIP(cfg).eval()
+    strings = validation_prompts(["MassShapeLabels"])["shapes"]
+    assert strings == ["Mass shape is unknown.", "Mass shape is oval.", "Mass shape is round.", "Mass shape is irregular."]
+    ptok = synthetic_prompt_tokens(strings, 77, 3000)
+    batch = synthetic_batch(16, S=77, vocab_size=3000, seed=21)
+    with torch.no_grad():
+        out = model(batch, validation=True)
+        te = head.L2Normalize.apply(model.text_projection_layer(model.encode_text({"text_tokens": ptok})))
+        _, _, sims = head.rows_forward(out["image_embeddings"].contiguous(), te.contiguous(), out["logit_scale"].reshape(1), 0, True)
+    sd = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+    bsd = {k[len("text_encoder.model."):]: v for k, v in sd.items() if k.startswith("text_encoder.model.")}
+    hid = E.bert_forward(bsd, ptok["input_ids"].cpu(), ptok["attention_mask"].cpu(), ptok["token_type_ids"].cpu())
+    tf = O.eos_pool(hid, ptok["attention_mask"].cpu())
+    wts = [sd[f"text_projection_layer.layers.{i}.weight"] for i in (0, 1)]
+    bs = [sd[f"text_projection_layer.layers.{i}.bias"] for i in (0, 1)]
+    te_ref = O.l2_normalize(O.multi_linear_head(tf, wts, bs))
+    iw = [sd[f"image_projection_layer.layers.{i}.weight"] for i in (0, 1)]
+    ib = [sd[f"image_projection_layer.layers.{i}.bias"] for i in (0, 1)]
+    ie_ref = O.l2_normalize(O.multi_linear_head(batch["image_features"].cpu().flatten(1), iw, ib))
+    ref = (1 / 0.07) * ie_ref @ te_ref.t()
+    np.testing.assert_allclose(sims.cpu().numpy(), ref.numpy(), atol=0.2)      # bf16 towers/heads; |logit| <= 14.3
+    assert sims.shape == (16, 4)
