@@ -109,8 +109,8 @@ int mmg_colsum_bf16(const void* A, int lda, int M, int N, float* out, mmg_stream
 
 /* y = (x - mean) * rstd * gamma + beta over the last dim C of bf16 x[M,C]; mean/rstd (fp32 [M], nullable) are saved
  * for the backward.  patch != 0: row m = (n,h,w) of an [n,H,W] grid is written to the 2x2-patchified position
- * row (n,h/2,w/2), columns ((h&1)*2+(w&1))*C of a [M/4, 4C] matrix (ConvNeXt downsample: the following 2x2/s2
- * convolution becomes a GEMM).  Replaces nn.LayerNorm / LayerNorm2d of torchvision ConvNeXt and HF BERT
+ * row (n,h/2,w/2), columns ((h&1)*2+(w&1))*C of a [n*(H/2)*(W/2), 4C] matrix (ConvNeXt downsample: the following
+ * 2x2/s2 convolution becomes a GEMM; an odd last row / column is dropped, as that convolution does).  Replaces nn.LayerNorm / LayerNorm2d of torchvision ConvNeXt and HF BERT
  * (mmgclip/networks/encoder.py:53,156) and of MLPProjectionHead (mmgclip/networks/projection.py:100). */
 int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
                       float* mean, float* rstd, int M, int C, int patch, int H, int W, mmg_stream_t stream);
@@ -137,7 +137,8 @@ int mmg_avgpool_fwd(const void* x, float* y, int n, int HW, int C, mmg_stream_t 
 int mmg_avgpool_bwd(const float* dy, void* dx, int n, int HW, int C, mmg_stream_t stream);
 
 /* Stem im2col: fp32 pixels [n,Cin,H,W] -> bf16 rows (n,h/P,w/P) x (kh,kw,cin), zero-padded to Kp columns;
- * scale16 != 0 applies ((65535 x) - 32767.5)/32767.5 (mmgclip/networks/image_features.py:95-99). */
+ * scale16 != 0 applies ((65535 x) - 32767.5)/32767.5 (mmgclip/networks/image_features.py:95-99).  H, W need not be
+ * multiples of P: the remainder rows / columns are ignored, as a stride-P convolution does. */
 int mmg_patchify(const float* img, void* out, int n, int Cin, int H, int W, int P, int Kp, int scale16,
                  mmg_stream_t stream);
 

@@ -32,9 +32,11 @@ struct LNArgs {
     int nt;                          // stream the output past L2 (tensor larger than the Infinity Cache)
 };
 
+// returns (size_t)-1 for pixels of an odd last row / column: a 2x2 stride-2 convolution never reads them
 __device__ __forceinline__ size_t ln_out_offset(const LNArgs& a, int m, int ld) {
     if (!a.patch) return (size_t)m * ld;
     const int w = m % a.W, h = (m / a.W) % a.H, n = m / (a.W * a.H);
+    if (h >= (a.H & ~1) || w >= (a.W & ~1)) return (size_t)-1;
     const size_t prow = ((size_t)n * (a.H / 2) + (h >> 1)) * (a.W / 2) + (w >> 1);
     return prow * ld + ((h & 1) * 2 + (w & 1)) * a.C;
 }
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const LNArgs a) {
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mu) * rs * a.gamma[c * 8 + e] + a.beta[c * 8 + e];
-                store16_stream(a.y + obase + c * 8, pack8(o), a.nt);
+                if (obase != (size_t)-1) store16_stream(a.y + obase + c * 8, pack8(o), a.nt);
             }
         }
         if (gl == 0) {
@@ -215,8 +217,7 @@ static int launch_ln(const LNArgs& a, hipStream_t stream) {
 
 static int ln_check(const char* who, int M, int C, int patch, int H, int W) {
     MMG_CHECK_ARG(M > 0 && C >= 8 && C % 8 == 0 && C <= 4096, "%s: M=%d C=%d (C must be a multiple of 8, <= 4096)", who, M, C);
-    MMG_CHECK_ARG(!patch || (H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && M % (H * W) == 0),
-                  "%s: patchified layout needs even H=%d W=%d dividing M=%d", who, H, W, M);
+    MMG_CHECK_ARG(!patch || (H > 1 && W > 1 && M % (H * W) == 0), "%s: patchified layout needs H=%d W=%d dividing M=%d", who, H, W, M);
     return 0;
 }
 
@@ -238,6 +239,7 @@ MMG_API int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, 
                               const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta, int M, int C,
                               int patch, int H, int W, const void* add, int ldadd, hipStream_t stream) {
     if (ln_check("mmg_layernorm_bwd", M, C, patch, H, W)) return 1;
+    MMG_CHECK_ARG(!patch || (H % 2 == 0 && W % 2 == 0), "mmg_layernorm_bwd: training through the patchified layout needs even H=%d W=%d", H, W);
     MMG_CHECK_ARG(dy && x && mean && rstd && gamma && dx && ((dgamma == nullptr) == (dbeta == nullptr)) &&
                       ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldx >= C && lddx >= C,
                   "mmg_layernorm_bwd: bad pointer or leading dimension");
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 }
 MMG_API int mmg_patchify(const float* img, void* out, int n, int Cin, int H, int W, int P, int Kp, int scale16,
                          hipStream_t stream) {
-    MMG_CHECK_ARG(img && out && n > 0 && Cin > 0 && P > 0 && H % P == 0 && W % P == 0 && Kp >= P * P * Cin && Kp % 8 == 0,
+    MMG_CHECK_ARG(img && out && n > 0 && Cin > 0 && P > 0 && H >= P && W >= P && Kp >= P * P * Cin && Kp % 8 == 0,
                   "mmg_patchify: bad argument (H=%d W=%d P=%d Cin=%d Kp=%d)", H, W, P, Cin, Kp);
     const size_t rows = (size_t)n * (H / P) * (W / P);
     size_t total = rows * Kp;

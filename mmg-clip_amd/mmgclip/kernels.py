@@ -17,7 +17,7 @@ def layernorm_fwd(x, gamma, beta, eps, patch_hw=None, want_stats=True):
         patch, H, W = 0, 0, 0
     else:
         H, W = patch_hw
-        y = torch.empty(M // 4, 4 * C, device=x.device, dtype=BF16)
+        y = torch.empty((M // (H * W)) * (H // 2) * (W // 2), 4 * C, device=x.device, dtype=BF16)
         patch = 1
     mean = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None

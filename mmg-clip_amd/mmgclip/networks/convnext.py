@@ -249,11 +249,23 @@ class ConvNextTower(nn.Module):
                      4 * C, stream())
 
     # ---- public -----------------------------------------------------------------------------------------------
+    def feature_map_shape(self, H, W):
+        """(h, w) of the last stage for an H x W input (floor at every stride, e.g. 1906 x 818 -> 59 x 25)."""
+        h, w = H // 4, W // 4
+        for _ in range(3):
+            h, w = h // 2, w // 2
+        return h, w
+
     def forward(self, images):
         _hip.require_gpu(images)
+        if images.shape[-2] < 32 or images.shape[-1] < 32:
+            raise ValueError(f"ConvNeXt needs at least 32x32 pixels, got {tuple(images.shape)}")
         self._materialize(images.device)
         self._pname = {id(m): "features." + n for n, m in self.model.features.named_modules()}
         needs_grad = torch.is_grad_enabled() and self._arena.any_trainable()
+        if needs_grad and (images.shape[-2] % 32 or images.shape[-1] % 32):
+            raise NotImplementedError("training the ConvNeXt tower needs H and W to be multiples of 32 (inference accepts any "
+                                      "size >= 32: strided layers drop the remainder exactly as torch's convolutions do)")
         return _ConvNextFn.apply(self, images.float().contiguous(), self._anchor if needs_grad else None)
 
 

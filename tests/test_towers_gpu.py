@@ -172,3 +172,42 @@ def test_vit_tower_long_sequence_path(dev):
                  "encoder.layers.encoder_layer_1.mlp.0.weight", "encoder.pos_embedding"):
         r, c = _rel(tower.model.get_parameter(name).grad, osd[name].grad)
         assert c > 0.99 and r < 0.12, (name, r, c)
+
+
+def test_feature_extractor_full_resolution_geometry_and_file_format(dev, tmp_path):
+    """Offline extraction (reference image_features.py:85-117): odd full-resolution sizes floor like torch's strided
+    convolutions ([1,1,H,W] -> [1,768,H/32,W/32] -> [1,768,1,1], cf. 1906x818 -> 59x25 in the notebook), HF/torchvision
+    layout state dict in, one `.pth` [1,768,1,1] fp32 file per image out."""
+    import pandas as pd
+    from PIL import Image
+    from mmgclip.config import Config
+    from mmgclip.networks.convnext import build_features
+    from mmgclip.networks.image_features import ImageFeatureExtractor, load_image
+    torch.manual_seed(0)
+    feats = build_features("tiny", in_chans=1)
+    _randomize(feats, 15)
+    sd = {"features." + k: v for k, v in feats.state_dict().items()}
+    ckpt = tmp_path / "convnext_tiny.pth"
+    torch.save(sd, ckpt)
+    h, w = 190, 117                                             # deliberately not multiples of 4 / 32
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(2):
+        arr = (rng.random((h, w)) * 65535).astype(np.uint16)
+        p = tmp_path / "2D_100micron" / "0" / f"p{i}" / f"img{i}.png"
+        p.parent.mkdir(parents=True, exist_ok=True)
+        Image.fromarray(arr).save(p)
+        paths.append(str(p))
+    cfg = Config.wrap({"networks": {"image_encoder": {"convnext_tiny_clf_path": str(ckpt)}}, "base": {"features_export_dir": str(tmp_path / "out")}})
+    ex = ImageFeatureExtractor(config=cfg, dataset=pd.DataFrame({"image_path": paths + [str(tmp_path / "missing.png")]}))
+    assert ex.image_encoder._tower.feature_map_shape(1906, 818) == (59, 25)
+    ex.extract()
+    assert (tmp_path / "out" / "failed.txt").exists()           # the missing file is logged, not fatal
+    for i, pth in enumerate(paths):
+        f = torch.load(tmp_path / "out" / "0" / f"p{i}" / f"img{i}.pth")
+        assert f.shape == (1, 768, 1, 1) and f.dtype == torch.float32
+        x = load_image(pth).unsqueeze(0)
+        ref, fmap = E.convnext_forward(sd, x, scale16=True)
+        assert fmap.shape[-2:] == (h // 32, w // 32)
+        r, c = _rel(f, ref)
+        assert r < 3e-2 and c > 0.999, (r, c)
