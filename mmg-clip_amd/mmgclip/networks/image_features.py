@@ -75,4 +75,79 @@ class ImageFeatureExtractor:
                         fh.write(row['image_path'] + '\n' + str(e) + '\n\n')
 
 
-ImagesFeatureExtractor = ImageFeatureExtractor
+class StudyFeatureExtractor:
+    """Per-exam features (reference image_features.py:124-263): the first `n_images_per_study` files of each `study_path`
+    go through the tower, then `concatenate_features_method` in {maxpool, avgpool, stack, concat} joins the [768] vectors;
+    one `<8-digit patient id>.pth` per study.  Views of one study that share a size run as one tower launch."""
+
+    def __init__(self, config=None, dataset=None):
+        assert config is not None, 'Error in initializing the feature extractor. Missing training config object.'
+        self.config = config
+        self.dataset = self._validate_dataset(dataset)
+        self.export_dir = os.path.join(self.config.base.features_export_dir)
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.image_encoder = ConvNextTiny()
+        self.image_encoder.from_pretrained(self.config.networks.image_encoder.convnext_tiny_clf_path)
+        self.image_encoder.to(self.device).eval()
+
+    def _validate_dataset(self, dataset):
+        import pandas as pd
+        if isinstance(dataset, pd.DataFrame):
+            if 'study_path' not in dataset.columns:
+                raise ValueError("Error in the `dataset` dataframe passed. The dataframe doesn't contain the following column `study_path`.")
+        elif isinstance(dataset, str):
+            raise NotImplementedError('Handling a string directory dataset is not yet implemented.')
+        else:
+            raise ValueError("Missing value for `dataset`. Please pass a valid Path or a dataset dataframe.")
+        return dataset
+
+    def _get_patient_id(self, path):
+        import re
+        match = re.search(r'\d{8}', path)
+        if match:
+            return match.group()
+
+    def _encode_views(self, paths):
+        views = [(65535.0 * load_image(p) - 32767.5) / 32767.5 for p in paths]
+        feats = [None] * len(views)
+        by_size = {}
+        for i, v in enumerate(views):
+            by_size.setdefault(tuple(v.shape), []).append(i)
+        for idx in by_size.values():
+            out = self.image_encoder(torch.stack([views[i] for i in idx]).to(self.device))   # [k,768,1,1]
+            for j, i in enumerate(idx):
+                feats[i] = out[j].reshape(-1)
+        return feats
+
+    def extract(self):
+        dcfg = self.config.dataset.config
+        method, n_views = dcfg.concatenate_features_method, dcfg.n_images_per_study
+        logger.info(f"Extracting and exporting features into {self.export_dir} directory.")
+        logger.info(f"Concatenating {n_views} images using {method} method.")
+        with torch.no_grad():
+            for _, row in self.dataset.iterrows():
+                study_path = row['study_path']
+                try:
+                    names = os.listdir(study_path)[:n_views]
+                    feats = self._encode_views([os.path.join(study_path, n) for n in names])
+                    if method == "maxpool":
+                        joint = torch.stack(feats, dim=0).max(dim=0)[0]
+                    elif method == "concat":
+                        joint = torch.cat(feats, dim=0)
+                    elif method == "stack":
+                        joint = torch.stack(feats, dim=0)
+                    elif method == "avgpool":
+                        joint = torch.stack(feats, dim=0).mean(dim=0)
+                    else:
+                        raise ValueError("Not implemented feature vector concatenation method")
+                    rel = study_path.split('2D_100micron/')[-1] if '2D_100micron/' in study_path else os.path.basename(study_path.rstrip('/'))
+                    out_dir = os.path.join(self.export_dir, rel)
+                    create_directory_if_not_exists(out_dir)
+                    torch.save(joint.detach().cpu(), os.path.join(out_dir, '{}.pth'.format(self._get_patient_id(path=study_path))))
+                except Exception as e:                                                        # noqa: BLE001 (as the reference)
+                    with open(os.path.join(self.export_dir, 'failed.txt'), "a") as fh:
+                        fh.write(study_path + '\n' + str(e) + '\n\n')
+
+
+image_feature_extractor = ImageFeatureExtractor
+study_feature_extractor = StudyFeatureExtractor

@@ -2,6 +2,8 @@
 
 Tolerances: activations/weights are bf16 on the device (8 bits of mantissa), the oracle is fp32; features agree to
 ~1e-2 relative, gradients are compared by cosine similarity (> 0.995) and relative L2 error (< 6e-2)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -211,3 +213,61 @@ def test_feature_extractor_full_resolution_geometry_and_file_format(dev, tmp_pat
         assert fmap.shape[-2:] == (h // 32, w // 32)
         r, c = _rel(f, ref)
         assert r < 3e-2 and c > 0.999, (r, c)
+
+
+def test_study_feature_extractor_pools_views(dev, tmp_path):
+    """StudyFeatureExtractor (reference image_features.py:187-263): <=n views per exam, maxpool / avgpool / stack."""
+    import pandas as pd
+    from PIL import Image
+    from mmgclip.config import Config
+    from mmgclip.networks.convnext import build_features
+    from mmgclip.networks.image_features import StudyFeatureExtractor, load_image
+    torch.manual_seed(1)
+    feats = build_features("tiny", in_chans=1)
+    _randomize(feats, 16)
+    sd = {"features." + k: v for k, v in feats.state_dict().items()}
+    ckpt = tmp_path / "convnext_tiny.pth"
+    torch.save(sd, ckpt)
+    rng = np.random.default_rng(1)
+    study = tmp_path / "2D_100micron" / "0" / "12" / "01234567" / "st01"
+    study.mkdir(parents=True)
+    for i, (h, w) in enumerate([(96, 64), (96, 64), (70, 90)]):
+        Image.fromarray((rng.random((h, w)) * 255).astype(np.uint8)).save(study / f"v{i}.png")
+    names = os.listdir(study)[:4]
+    ref = torch.stack([E.convnext_forward(sd, load_image(str(study / n)).unsqueeze(0), scale16=True)[0].reshape(-1) for n in names])
+    for method, want in (("maxpool", ref.max(0)[0]), ("avgpool", ref.mean(0)), ("stack", ref)):
+        cfg = Config.wrap({"networks": {"image_encoder": {"convnext_tiny_clf_path": str(ckpt)}},
+                           "base": {"features_export_dir": str(tmp_path / method)},
+                           "dataset": {"config": {"n_images_per_study": 4, "concatenate_features_method": method}}})
+        StudyFeatureExtractor(config=cfg, dataset=pd.DataFrame({"study_path": [str(study)]})).extract()
+        assert not (tmp_path / method / "failed.txt").exists(), (tmp_path / method / "failed.txt").read_text()
+        got = torch.load(tmp_path / method / "0" / "12" / "01234567" / "st01" / "01234567.pth")
+        assert got.shape == want.shape
+        r, c = _rel(got, want)
+        assert r < 3e-2 and c > 0.999, (method, r, c)
+
+
+def test_bert_encoder_loads_huggingface_directory(dev, tmp_path):
+    """a `BertModel.save_pretrained` directory (config.json + model.safetensors) drops into BertEncoder
+    (reference encoder.py:131-156 calls AutoModel.from_pretrained on a name or local path); output = HF last_hidden_state."""
+    transformers = pytest.importorskip("transformers")
+    torch.manual_seed(3)
+    hf_cfg = transformers.BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                     intermediate_size=512, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                                     attention_probs_dropout_prob=0.0)
+    hf = transformers.BertModel(hf_cfg, add_pooling_layer=False).eval()
+    hf.save_pretrained(tmp_path / "bert")
+    from mmgclip.networks.encoder import BertEncoder
+    enc = BertEncoder(pretrained=str(tmp_path / "bert")).to(dev)
+    assert enc.model_output_dimension == 128
+    B, S = 4, 24
+    ids = torch.randint(1, 300, (B, S))
+    lens = torch.tensor([24, 9, 17, 3])
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    ids = ids * mask
+    with torch.no_grad():
+        want = hf(input_ids=ids, attention_mask=mask, token_type_ids=torch.zeros_like(ids)).last_hidden_state
+        got = enc({"input_ids": ids.to(dev), "attention_mask": mask.to(dev), "token_type_ids": torch.zeros_like(ids).to(dev)}).float().cpu()
+    valid = mask.bool()
+    r, c = _rel(got[valid], want[valid])
+    assert r < 3e-2 and c > 0.999, (r, c)
