@@ -172,6 +172,22 @@ int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, const voi
 int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int H, int W, int C,
                       mmg_stream_t stream);
 
+/* ---- fused ConvNeXt block MLP (C in {96,128,192,256}) ---------------------------------------------------------- */
+
+/* Number of bf16 elements of the packed weight image (8C^2 forward, 12C^2 backward); 0 when C is unsupported. */
+long long mmg_cnblock_packed_elems(int C, int backward);
+/* Pack W1 fp32 [4C,C], W2 fp32 [C,4C] (torchvision CNBlock.block[3] / block[5]) into the per-chunk LDS images the fused
+ * kernels stream (layout: csrc/cnblock_mlp.hip).  backward != 0 builds [W1 | gamma*W2^T | W1^T] and needs gamma [C]. */
+int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamma, void* packed, int C, int backward,
+                             mmg_stream_t stream);
+/* y = residual + gamma * ( GELU( LayerNorm(xd; ln_w, ln_b, eps) W1^T + b1 ) W2^T + b2 ), rows of [M,C] bf16.
+ * Replaces CNBlock.block[2..5] + layer_scale + residual of torchvision ConvNeXt (mmgclip/networks/encoder.py:53) in one
+ * launch: the 4C-wide hidden row stays in registers.  hpre (bf16 [M,4C], pre-GELU) and mean/rstd (fp32 [M]) are optional (all three or none)
+ * outputs for a backward that does not recompute them. */
+int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
+                        const float* b1, const float* b2, const float* gamma, const void* residual, void* y, void* hpre,
+                        float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
+
 /* ---- BERT attention / embeddings / pooling -------------------------------------------------------------------- */
 
 /* ctx[B*S,Hd] = per-head softmax(Q K^T * scale + key mask) V with qkv = [B*S, q|k|v] bf16 (head h at columns h*64

@@ -1,0 +1,312 @@
+// Fused ConvNeXt block MLP for the narrow stages (C <= 256):   y = x + gamma * ( GELU( LN(d) W1^T + b1 ) W2^T + b2 )
+//
+// Replaces, for torchvision's CNBlock (reference: mmgclip/networks/encoder.py:53 runs `model.features`; module tree in
+// notebooks/clf_convnext_tiny_experimental.ipynb cell 3: LayerNorm -> Linear(C,4C) -> GELU -> Linear(4C,C) -> layer_scale
+// -> residual), the LayerNorm kernel + two GEMM launches whose 4C-wide intermediates made stages 1-2 HBM-bound
+// (17C bytes/pixel of traffic in the forward).  Here the 4C hidden row never leaves the CU: HBM traffic is d (C) in, x (C)
+// in, y (C) out.
+//
+// Structure (one workgroup = 4 waves = 128 rows, each wave owns 32 rows end to end):
+//   * the wave loads its rows of d straight into MFMA B-operand fragments (lane = row, 8 consecutive k), LayerNorm is done
+//     in registers (row statistics need two xor-shuffles: the 4 lanes {l, l^16, l^32, l^48} share a row);
+//   * the two weight matrices are pre-packed on the device (mmg_cnblock_pack_weights) into per-chunk LDS images, so a
+//     chunk (NC hidden columns: NC x C of W1 and C x NC of W2) is one linear 16-byte global_load_lds stream, double
+//     buffered, one barrier per chunk; fragment reads are conflict-free ds_read_b128 by construction (16 consecutive
+//     granules per 16-lane group);
+//   * both MFMAs are issued swapped (A := weight fragment), so the accumulator of GEMM 1 leaves lane l with row l&15 and 4
+//     consecutive hidden columns: bias + GELU are applied in place and two such tiles ARE the B operand of GEMM 2's
+//     16x16x32 step (the k-order this implies is folded into the packing of W2) - no LDS round trip for the hidden row.
+// The bound is the fp32 VALU (erf-GELU, ~18 ops per hidden element = 3x the MFMA time at C=96), then HBM.
+#include "common.h"
+
+#define MLP_THREADS 256
+#define MLP_BM 128
+
+struct MlpFwd {
+    const bf16_t* xd;                       // [M,C] depthwise output
+    const float* ln_w; const float* ln_b; float eps;
+    const bf16_t* wt;                       // packed chunks
+    const float* b1; const float* b2; const float* gamma;
+    const bf16_t* res;                      // [M,C] block input
+    bf16_t* y;                              // [M,C]
+    bf16_t* hpre;                           // optional [M,4C] pre-GELU hidden (for an unfused backward)
+    float* mean; float* rstd;               // optional [M]
+    long M; int ntiles;
+};
+
+__device__ __forceinline__ void mlp_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int C> struct MlpCfg {
+    static constexpr int NC = (C <= 128) ? 64 : 32;
+    static constexpr int WGS = (C <= 96) ? 3 : (C <= 192 ? 2 : 1);     // workgroups per CU the registers / LDS allow
+};
+
+// ---- weight packing --------------------------------------------------------------------------------------------------
+// chunk j (hidden columns j*NC .. +NC) is a sequence of parts, each an LDS image of NC*C bf16:
+//   A-type part : (C/8) k-granules x NC rows x 8   element (n, c), K = c           (weight fragment of  . x [*, C]^T)
+//   B-type part : (NC/8) k-granules x C rows x 8   element (c, n), K = n PERMUTED  (weight fragment of  hidden x [C, *]^T)
+// K permutation of a B-type part inside each group of 32 hidden columns: slot 8q+j holds column (j<4 ? 4q+j : 16+4q+j-4),
+// the order in which two swapped-MFMA accumulator tiles present the hidden row as a B operand.
+// A source is W1-like ([4C, C], element (n, c) at n*C + c) or W2-like ([C, 4C], element (n, c) at c*4C + n); `scale` ([C],
+// optional) multiplies by scale[c] (folds the layer scale into W2^T for the backward).
+struct PackPart { const float* src; int w2_like; const float* scale; int btype; };
+struct PackArgs { PackPart part[3]; int parts; bf16_t* out; int C, NC; };
+
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const PackArgs a) {
+    const int C = a.C, NC = a.NC, H4 = 4 * C;
+    const long per_part = (long)NC * C, per_chunk = per_part * a.parts, total = per_chunk * (H4 / NC);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / per_chunk);
+        long off = e - (long)j * per_chunk;
+        const int pi = (int)(off / per_part);
+        off -= (long)pi * per_part;
+        const PackPart pp = a.part[pi];
+        int n, c;
+        if (!pp.btype) {
+            const int kg = (int)(off / (NC * 8)), nn = (int)((off / 8) % NC), jj = (int)(off % 8);
+            n = j * NC + nn; c = 8 * kg + jj;
+        } else {
+            const int kg = (int)(off / (C * 8)), jj = (int)(off % 8);
+            c = (int)((off / 8) % C);
+            const int slot = 8 * kg + jj, g32 = slot >> 5, q = (slot & 31) >> 3, j8 = slot & 7;
+            n = j * NC + 32 * g32 + (j8 < 4 ? 4 * q + j8 : 16 + 4 * q + (j8 - 4));
+        }
+        float v = pp.w2_like ? pp.src[(long)c * H4 + n] : pp.src[(long)n * C + c];
+        if (pp.scale) v *= pp.scale[c];
+        a.out[e] = f2bf(v);
+    }
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------
+template <int C, bool SAVE>
+__global__ __launch_bounds__(MLP_THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_kernel(const MlpFwd p) {
+    constexpr int NC = MlpCfg<C>::NC;
+    constexpr int KS1 = C / 32, CT = C / 16, NSUB = NC / 32, NCH = 4 * C / NC;
+    constexpr int PART = NC * C * 2, CHUNK = 2 * PART, LOADS = CHUNK / 16 / MLP_THREADS;
+    static_assert(CHUNK % (16 * MLP_THREADS) == 0, "chunk must be a whole number of 16-byte granules per thread");
+    static_assert(NCH % 2 == 0, "ring parity is carried across tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_lnw = reinterpret_cast<float*>(smem + 2 * CHUNK);   // [C] [C] [4C] [C] [C]
+    float* s_lnb = s_lnw + C;
+    float* s_b1 = s_lnb + C;
+    float* s_b2 = s_b1 + 4 * C;
+    float* s_gm = s_b2 + C;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lg = lane >> 4;
+    char* lds_wave = smem + (tid & ~63) * 16;
+    const char* wsrc = reinterpret_cast<const char*>(p.wt) + tid * 16;
+
+    auto stage = [&](int buf, int ch) {
+        const char* s = wsrc + (size_t)ch * CHUNK;
+#pragma unroll
+        for (int it = 0; it < LOADS; ++it) mlp_glds16(s + it * (MLP_THREADS * 16), lds_wave + buf * CHUNK + it * (MLP_THREADS * 16));
+    };
+    if ((int)blockIdx.x < p.ntiles) stage(0, 0);
+    for (int i = tid; i < C; i += MLP_THREADS) {
+        s_lnw[i] = p.ln_w[i]; s_lnb[i] = p.ln_b[i]; s_b2[i] = p.b2[i]; s_gm[i] = p.gamma[i];
+    }
+    for (int i = tid; i < 4 * C; i += MLP_THREADS) s_b1[i] = p.b1[i];
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const long row0 = (long)tile * MLP_BM + wave * 32 + li;          // + 16*mi
+        // ---- rows of d -> LayerNorm -> bf16 B-operand fragments ---------------------------------------------------------
+        bf16x8 xf[2][KS1];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const long row = row0 + 16 * mi;
+            const long rr = row < p.M ? row : p.M - 1;
+            uint4 raw[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) raw[ks] = *reinterpret_cast<const uint4*>(p.xd + rr * C + 32 * ks + 8 * lg);
+            float v[KS1][8];
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const unsigned w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[ks][2 * e] = bf2f_lo(w[e]); v[ks][2 * e + 1] = bf2f_hi(w[e]);
+                    s += v[ks][2 * e] + v[ks][2 * e + 1];
+                }
+            }
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            const float mean = s * (1.0f / C);
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mean; q = fmaf(d, d, q); }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q * (1.0f / C) + p.eps);
+            if (SAVE && lg == 0 && row < p.M) { p.mean[row] = mean; p.rstd[row] = rstd; }
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_lnw + 32 * ks + 8 * lg);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_lnw + 32 * ks + 8 * lg + 4);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(s_lnb + 32 * ks + 8 * lg);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(s_lnb + 32 * ks + 8 * lg + 4);
+                const float g[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                const float b[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                unsigned o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack2bf(fmaf((v[ks][2 * e] - mean) * rstd, g[2 * e], b[2 * e]),
+                                   fmaf((v[ks][2 * e + 1] - mean) * rstd, g[2 * e + 1], b[2 * e + 1]));
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                xf[mi][ks] = __builtin_bit_cast(bf16x8, (u32x4_t{o[0], o[1], o[2], o[3]}));
+            }
+        }
+
+        f32x4 yacc[2][CT];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) yacc[mi][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- hidden chunks ---------------------------------------------------------------------------------------------
+        for (int ch = 0; ch < NCH; ++ch) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ch + 1 < NCH) stage((ch + 1) & 1, ch + 1);
+            else if (tile + (int)gridDim.x < p.ntiles) stage(0, 0);
+            const char* wb = smem + (ch & 1) * CHUNK;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                // accumulators start from the bias (lane owns 4 consecutive hidden columns of its rows)
+                const int n0 = ch * NC + sub * 32 + 4 * lg;
+                const f32x4 bia0 = *reinterpret_cast<const f32x4*>(s_b1 + n0);
+                const f32x4 bia1 = *reinterpret_cast<const f32x4*>(s_b1 + n0 + 16);
+                f32x4 hacc[2][2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) { hacc[mi][0] = bia0; hacc[mi][1] = bia1; }
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (((4 * ks + lg) * NC + (2 * sub + tt) * 16 + li) << 4));
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+                            hacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mi][ks], hacc[mi][tt], 0, 0, 0);
+                    }
+                }
+                bf16x8 gf[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const f32x4 h0 = hacc[mi][0], h1 = hacc[mi][1];
+                    if (SAVE) {
+                        const long row = row0 + 16 * mi;
+                        if (row < p.M) {
+                            bf16_t* hp = p.hpre + row * (4 * C) + n0;
+                            *reinterpret_cast<uint2*>(hp) = make_uint2(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]));
+                            *reinterpret_cast<uint2*>(hp + 16) = make_uint2(pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3]));
+                        }
+                    }
+                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                    gf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{pack2bf(gelu_f(h0[0]), gelu_f(h0[1])), pack2bf(gelu_f(h0[2]), gelu_f(h0[3])),
+                                                                 pack2bf(gelu_f(h1[0]), gelu_f(h1[1])), pack2bf(gelu_f(h1[2]), gelu_f(h1[3]))}));
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + PART + (((4 * sub + lg) * C + ct * 16 + li) << 4));
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        yacc[mi][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf[mi], yacc[mi][ct], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- y = x + gamma * (acc + b2) -----------------------------------------------------------------------------------
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const long row = row0 + 16 * mi;
+            if (row < p.M) {
+                uint2 rv[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) rv[ct] = *reinterpret_cast<const uint2*>(p.res + row * C + ct * 16 + 4 * lg);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f32x4 b2 = *reinterpret_cast<const f32x4*>(s_b2 + ct * 16 + 4 * lg);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_gm + ct * 16 + 4 * lg);
+                    const f32x4 a = yacc[mi][ct];
+                    const float o0 = fmaf(gm[0], a[0] + b2[0], bf2f_lo(rv[ct].x)), o1 = fmaf(gm[1], a[1] + b2[1], bf2f_hi(rv[ct].x));
+                    const float o2 = fmaf(gm[2], a[2] + b2[2], bf2f_lo(rv[ct].y)), o3 = fmaf(gm[3], a[3] + b2[3], bf2f_hi(rv[ct].y));
+                    *reinterpret_cast<uint2*>(p.y + row * C + ct * 16 + 4 * lg) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+                }
+            }
+        }
+    }
+}
+
+template <int C>
+static int launch_mlp_fwd(const MlpFwd& p, hipStream_t stream) {
+    constexpr int NC = MlpCfg<C>::NC;
+    const size_t lds = 2 * (2 * NC * C * 2) + (size_t)8 * C * sizeof(float);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t pr;
+        (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    const int per_cu = MlpCfg<C>::WGS;
+    const int grid = p.ntiles < per_cu * cus ? p.ntiles : per_cu * cus;
+    if (p.hpre) {
+        mmg_allow_lds(cnblock_mlp_fwd_kernel<C, true>, lds);
+        hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, true>), dim3(grid), dim3(MLP_THREADS), lds, stream, p);
+    } else {
+        mmg_allow_lds(cnblock_mlp_fwd_kernel<C, false>, lds);
+        hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, false>), dim3(grid), dim3(MLP_THREADS), lds, stream, p);
+    }
+    MMG_LAUNCH_CHECK("mmg_cnblock_mlp_fwd");
+    return 0;
+}
+
+static bool mlp_supported(int C) { return C == 96 || C == 128 || C == 192 || C == 256; }
+
+MMG_API long long mmg_cnblock_packed_elems(int C, int backward) {
+    if (!mlp_supported(C)) return 0;
+    return (long long)(backward ? 3 : 2) * 4 * C * C;
+}
+
+MMG_API int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamma, void* packed, int C, int backward,
+                                     hipStream_t stream) {
+    MMG_CHECK_ARG(w1 && w2 && packed, "mmg_cnblock_pack_weights: null pointer");
+    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_pack_weights: C=%d not in {96,128,192,256}", C);
+    MMG_CHECK_ARG(!backward || gamma, "mmg_cnblock_pack_weights: the backward image needs the layer scale");
+    PackArgs a{};
+    a.out = (bf16_t*)packed; a.C = C; a.NC = C <= 128 ? 64 : 32;
+    a.part[0] = PackPart{w1, 0, nullptr, 0};                       // W1 rows n, K = c            (hidden = x W1^T)
+    if (!backward) {
+        a.parts = 2;
+        a.part[1] = PackPart{w2, 1, nullptr, 1};                   // W2 rows c, K = n            (y = g W2^T)
+    } else {
+        a.parts = 3;
+        a.part[1] = PackPart{w2, 1, gamma, 0};                     // gamma*W2^T rows n, K = c    (dG = dy (gamma W2))
+        a.part[2] = PackPart{w1, 0, nullptr, 1};                   // W1^T rows c, K = n          (dx = dH W1)
+    }
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3(256), dim3(256), 0, stream, a);
+    MMG_LAUNCH_CHECK("mmg_cnblock_pack_weights");
+    return 0;
+}
+
+MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
+                                const float* b1, const float* b2, const float* gamma, const void* residual, void* y,
+                                void* hpre, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
+    MMG_CHECK_ARG(xd && ln_w && ln_b && packed && b1 && b2 && gamma && residual && y, "mmg_cnblock_mlp_fwd: null pointer");
+    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_mlp_fwd: C=%d not in {96,128,192,256}", C);
+    MMG_CHECK_ARG(M > 0 && M < (1L << 31) * MLP_BM, "mmg_cnblock_mlp_fwd: bad M=%lld", M);
+    MMG_CHECK_ARG((mean == nullptr) == (hpre == nullptr) && (rstd == nullptr) == (hpre == nullptr),
+                  "mmg_cnblock_mlp_fwd: hpre, mean and rstd are saved together or not at all");
+    MlpFwd p{(const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed, b1, b2, gamma, (const bf16_t*)residual, (bf16_t*)y,
+             (bf16_t*)hpre, mean, rstd, (long)M, (int)((M + MLP_BM - 1) / MLP_BM)};
+    switch (C) {
+        case 96: return launch_mlp_fwd<96>(p, stream);
+        case 128: return launch_mlp_fwd<128>(p, stream);
+        case 192: return launch_mlp_fwd<192>(p, stream);
+        default: return launch_mlp_fwd<256>(p, stream);
+    }
+}

@@ -62,30 +62,48 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // erf-GELU, as torch.nn.GELU() / HF "gelu".  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
-// resolution of the tensors it is applied to): one v_exp + one v_rcp + 6 FMAs instead of libm erff's ~40 instructions.
-// It sits in GEMM epilogues, where the libm version cost more than the MFMA main loop.  Both helpers share the
-// exp(-x^2/2) between the erf tail and the Gaussian density.
-__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
-    const float ax = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));     // v_rcp_f32, 1 ulp
-    const float e = __expf(-ax * ax);                       // = exp(-x^2 / 2)
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float tail = 0.5f * poly * t * e;                 // 0.5 * erfc(|x|/sqrt2)
-    cdf = x >= 0.f ? 1.0f - tail : tail;
-    pdf = 0.3989422804014327f * e;
+// resolution of the tensors it is applied to).  It sits in GEMM epilogues and in the fused CNBlock MLP, where the VALU is
+// the bound, so the form is chosen for instruction count (13 VALU ops, 2 of them transcendental, no compare/select):
+//     s = |x| sqrt(log2(e)/2),  e = 2^(-s^2) = exp(-x^2/2),  t = 1/(1 + p |x|/sqrt2),  tail = 0.5 erfc(|x|/sqrt2) = q(t) t e
+//     GELU(x)  = max(x,0) - |x| tail = x/2 + |x| (1/2 - tail)   (x Phi(x) with Phi = 1 - tail for x >= 0, tail for x < 0)
+//     GELU'(x) = 0.5 + copysign(0.5 + w, x),  w = e (|x|/sqrt(2 pi) - q(t) t)      (= Phi(x) + x phi(x))
+__device__ __forceinline__ void gelu_core(float x, float& ax, float& e, float& qt) {
+    ax = fabsf(x);
+    const float s = ax * 0.84932180028801904f;                             // sqrt(log2(e) / 2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.27273172829f, s, 1.0f));  // p / sqrt(log2 e) ; v_rcp_f32, 1 ulp
+    e = __builtin_amdgcn_exp2f(-s * s);
+    float q = fmaf(0.5307027145f, t, -0.7265760135f);                      // 0.5 * A&S coefficients
+    q = fmaf(q, t, 0.7107068705f);
+    q = fmaf(q, t, -0.142248368f);
+    q = fmaf(q, t, 0.127414796f);
+    qt = q * t;
 }
 __device__ __forceinline__ float gelu_f(float x) {
-    float cdf, pdf;
-    gelu_parts(x, cdf, pdf);
-    return x * cdf;
+    float ax, e, qt;
+    gelu_core(x, ax, e, qt);
+    return fmaf(ax, fmaf(-qt, e, 0.5f), 0.5f * x);       // max(x,0) = 0.5 (x + |x|): no NaN-canonicalising v_max
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    float cdf, pdf;
-    gelu_parts(x, cdf, pdf);
-    return fmaf(x, pdf, cdf);
+    float ax, e, qt;
+    gelu_core(x, ax, e, qt);
+    const float w = e * fmaf(ax, 0.3989422804014327f, -qt);
+    return 0.5f + copysignf(0.5f + w, x);
+}
+// both at once (the backward epilogues need GELU(h) for the weight gradient and GELU'(h) for the data gradient)
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+    float ax, e, qt;
+    gelu_core(x, ax, e, qt);
+    g = fmaf(ax, fmaf(-qt, e, 0.5f), 0.5f * x);
+    const float w = e * fmaf(ax, 0.3989422804014327f, -qt);
+    dg = 0.5f + copysignf(0.5f + w, x);
+}
+// (kept for callers that want the two factors) cdf = Phi(x), pdf = phi(x)
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+    float ax, e, qt;
+    gelu_core(x, ax, e, qt);
+    const float tail = qt * e;
+    cdf = x >= 0.f ? 1.0f - tail : tail;
+    pdf = 0.3989422804014327f * e;
 }
 
 // 16-byte store that bypasses L2 allocation when `nt` (streaming outputs larger than the Infinity Cache)

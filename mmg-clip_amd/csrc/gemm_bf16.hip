@@ -117,12 +117,12 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
             if (g.epi == EPI_DGELU) {
                 // the activation itself (needed by the weight-gradient GEMM of the same layer) shares cdf/pdf with
                 // its derivative: emitting it here replaces a separate read-modify-write pass over the [M,N] tensor
-                float c0, p0, c1, p1;
-                gelu_parts(h0, c0, p0);
-                gelu_parts(h1, c1, p1);
-                v[2 * e] *= fmaf(h0, p0, c0);
-                v[2 * e + 1] *= fmaf(h1, p1, c1);
-                act[e] = pack2bf(h0 * c0, h1 * c1);
+                float a0, d0, a1, d1;
+                gelu_both(h0, a0, d0);
+                gelu_both(h1, a1, d1);
+                v[2 * e] *= d0;
+                v[2 * e + 1] *= d1;
+                act[e] = pack2bf(a0, a1);
             } else {
                 act[e] = pack2bf(fmaxf(h0, 0.f), fmaxf(h1, 0.f));
                 v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;

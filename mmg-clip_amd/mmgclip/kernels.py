@@ -4,6 +4,7 @@ Shapes follow the device layout: activations are bf16 row-major [rows, channels]
 """
 import torch
 
+from . import _hip
 from ._hip import call, ptr, stream
 
 BF16 = torch.bfloat16
@@ -93,6 +94,33 @@ def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None):
 
 def dwconv7_wgrad(x, dy, dw49, dbias, n, H, W, C):
     call("mmg_dwconv7_wgrad", ptr(x), ptr(dy), ptr(dw49), ptr(dbias), n, H, W, C, stream())
+
+
+def cnblock_supported(C):
+    return C in (96, 128, 192, 256)
+
+
+def cnblock_pack(w1, w2, gamma=None, backward=False):
+    """Packed bf16 weight image of the fused CNBlock MLP kernels (W1 fp32 [4C,C], W2 fp32 [C,4C])."""
+    C = w1.shape[1]
+    n = _hip.load().mmg_cnblock_packed_elems(C, 1 if backward else 0)
+    if n <= 0:
+        raise ValueError(f"fused CNBlock MLP: C={C} is not supported")
+    out = torch.empty(n, device=w1.device, dtype=BF16)
+    call("mmg_cnblock_pack_weights", ptr(w1), ptr(w2), ptr(gamma), ptr(out), C, 1 if backward else 0, stream())
+    return out
+
+
+def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_hpre=False, want_stats=False):
+    M, C = xd.shape
+    y = torch.empty_like(xd)
+    hpre = torch.empty(M, 4 * C, device=xd.device, dtype=BF16) if want_hpre else None
+    assert want_hpre == want_stats, "hpre and the LN statistics are saved together"
+    mean = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
+    call("mmg_cnblock_mlp_fwd", ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed), ptr(b1), ptr(b2), ptr(gamma),
+         ptr(residual), ptr(y), ptr(hpre), ptr(mean), ptr(rstd), M, C, stream())
+    return y, hpre, mean, rstd
 
 
 def attention_fwd(qkv, mask, B, S, heads, want_lse=True, force_long=False):

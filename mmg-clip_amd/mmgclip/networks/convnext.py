@@ -16,6 +16,8 @@ row-major GEMM and LayerNorm reads contiguous rows; the 2x2/4x4 stride=kernel co
 rows (the LayerNorm kernel writes the patchified layout directly).  Saved for backward per block and pixel: block input
 (C), depthwise output (C), pre-GELU hidden (4C) in bf16 + LN statistics; LN output and GELU output are rebuilt.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -80,9 +82,11 @@ class _TorchvisionLayout(nn.Module):
 class ConvNextTower(nn.Module):
     """pixels fp32 [n, Cin, H, W] in [0,1] (scale16=True applies the reference's 16-bit scaling) -> features [n, dims[-1]]."""
 
-    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=64):
+    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=64, fused_mlp=None):
         super().__init__()
         self.variant, self.in_chans, self.scale16, self.micro_batch = variant, in_chans, scale16, micro_batch
+        # narrow stages (C <= 256) run the CNBlock MLP as one fused launch; MMG_FUSED_MLP=0 keeps the GEMM pair
+        self.fused_mlp = (os.environ.get("MMG_FUSED_MLP", "1") != "0") if fused_mlp is None else bool(fused_mlp)
         self.dims, self.depths = CONFIGS[variant]["dims"], CONFIGS[variant]["depths"]
         self.model = _TorchvisionLayout(variant, in_chans)
         self.model_output_dimension = self.dims[-1]
@@ -127,6 +131,8 @@ class ConvNextTower(nn.Module):
                 wc[key + ".w2"] = K.cast_bf16(blk.block[5].weight.data)                      # [C, 4C]
                 wc[key + ".w2gt"] = K.transpose_cast_bf16(blk.block[5].weight.data,          # [4C, C] * gamma
                                                           blk.layer_scale.data.reshape(C))
+                if self.fused_mlp and K.cnblock_supported(C):                                # packed LDS images
+                    wc[key + ".mlp"] = K.cnblock_pack(blk.block[3].weight.data, blk.block[5].weight.data)
             if si < 3:
                 conv = f[2 + 2 * si][1].weight.data                                          # [2C, C, 2, 2]
                 wds = conv.permute(0, 2, 3, 1).reshape(conv.shape[0], -1).contiguous()       # [(kh,kw,ci)]
@@ -150,6 +156,14 @@ class ConvNextTower(nn.Module):
             for bi, blk in enumerate(f[1 + 2 * si]):
                 key = f"{si}.{bi}"
                 d = K.dwconv7(x, wc[key + ".w49"], blk.block[0].bias.data, n, h, w_, C)
+                if key + ".mlp" in wc:          # LN + Linear + GELU + Linear + layer scale + residual in one launch
+                    xn, hpre, mean, rstd = K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS,
+                                                             wc[key + ".mlp"], blk.block[3].bias.data, blk.block[5].bias.data,
+                                                             blk.layer_scale.data.reshape(C), x, want_hpre=save, want_stats=save)
+                    if save:
+                        saved[key] = (x, d, mean, rstd, hpre)
+                    x = xn
+                    continue
                 ln, mean, rstd = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=save)
                 hpre = torch.empty(x.shape[0], 4 * C, device=x.device, dtype=torch.bfloat16) if save else None
                 g = L.gemm_nt(ln, wc[key + ".w1"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre)

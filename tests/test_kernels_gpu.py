@@ -222,3 +222,32 @@ def test_attention_long_fwd_bwd(dev, B, S, heads, masked):
         ctx2, lse2 = K.attention_fwd(qkv, mask, B, S, heads)
         _close(ctx, ctx2, 1e-2, 1e-2)
         _close(lse, lse2, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("C,M", [(96, 128 * 5 + 37), (192, 300), (128, 129), (256, 200)])
+def test_fused_cnblock_mlp_forward_matches_unfused_reference(dev, C, M):
+    """mmg_cnblock_mlp_fwd = LN -> Linear(C,4C) -> GELU -> Linear(4C,C) -> layer scale -> + residual in one launch
+    (torchvision CNBlock.block[2..5]); fp32 torch of the same op on the same bf16 inputs / bf16-rounded weights."""
+    from mmgclip import kernels as K
+    g = torch.Generator().manual_seed(C + M)
+    xd = torch.randn(M, C, generator=g).to(torch.bfloat16)
+    res = torch.randn(M, C, generator=g).to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w1, b1 = torch.randn(4 * C, C, generator=g) / C ** 0.5, 0.1 * torch.randn(4 * C, generator=g)
+    w2, b2 = torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5, 0.1 * torch.randn(C, generator=g)
+    gamma = 0.3 + 0.7 * torch.rand(C, generator=g)
+    ln = torch.nn.functional.layer_norm(xd.float(), (C,), lnw, lnb, 1e-6).to(torch.bfloat16).float()
+    h = ln @ w1.to(torch.bfloat16).float().t() + b1
+    gl = torch.nn.functional.gelu(h).to(torch.bfloat16).float()
+    want = res.float() + gamma * (gl @ w2.to(torch.bfloat16).float().t() + b2)
+    d = lambda t: t.to(dev)   # noqa: E731
+    packed = K.cnblock_pack(d(w1), d(w2))
+    y, hpre, mean, rstd = K.cnblock_mlp_fwd(d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1), d(b2), d(gamma), d(res),
+                                            want_hpre=True, want_stats=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(y.float().cpu(), want, atol=3e-2, rtol=2e-2), float((y.float().cpu() - want).abs().max())
+    assert torch.allclose(hpre.float().cpu(), h, atol=3e-2, rtol=2e-2)
+    assert torch.allclose(mean.cpu(), xd.float().mean(1), atol=1e-5)
+    assert torch.allclose(rstd.cpu(), (xd.float().var(1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-4)
+    y2, _, _, _ = K.cnblock_mlp_fwd(d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1), d(b2), d(gamma), d(res))
+    assert torch.equal(y2, y)
