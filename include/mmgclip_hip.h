@@ -188,6 +188,16 @@ int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, fl
                         const float* b1, const float* b2, const float* gamma, const void* residual, void* y, void* hpre,
                         float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
 
+/* Data path of the CNBlock MLP backward in one launch (C in {96,128}; mmg_cnblock_mlp_bwd_supported tells): recomputes
+ * h = LN(xd) W1^T + b1 from the saved depthwise output, and writes g = GELU(h), dh = (dy gamma W2) * GELU'(h) (bf16 [M,4C],
+ * the operands of the weight-gradient GEMMs dW2 = dy^T g, dW1 = dh^T xln), xln = LN(xd) and dxln = dh W1 (bf16 [M,C]) plus the
+ * LN statistics for mmg_layernorm_bwd.  packed_bwd = mmg_cnblock_pack_weights(..., backward=1).  The forward then saves
+ * nothing 4C-wide.  (New capability: the reference never trains the image tower, mmgclip/networks/encoder.py:53.) */
+int mmg_cnblock_mlp_bwd_supported(int C);
+int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps,
+                        const void* packed_bwd, const float* b1, void* dh, void* g, void* xln, void* dxln, float* mean,
+                        float* rstd, long long M, int C, mmg_stream_t stream);
+
 /* ---- BERT attention / embeddings / pooling -------------------------------------------------------------------- */
 
 /* ctx[B*S,Hd] = per-head softmax(Q K^T * scale + key mask) V with qkv = [B*S, q|k|v] bf16 (head h at columns h*64

@@ -242,6 +242,207 @@ __global__ __launch_bounds__(MLP_THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_k
     }
 }
 
+// ---- backward (data path) ---------------------------------------------------------------------------------------------
+// Same skeleton with three weight parts per chunk [W1 | gamma*W2^T | W1^T]:  per 32 hidden columns the wave recomputes the
+// pre-activation h = LN(d) W1^T + b1, forms dG = dy (gamma W2) next to it, applies GELU / GELU' in registers, writes
+// g = GELU(h) and dh = dG GELU'(h) (bf16, the operands of the two weight-gradient GEMMs) and feeds dh straight into the
+// accumulation of d LN-out = dh W1.  Nothing 4C-wide is READ from HBM: the forward saves no hidden tensor.
+struct MlpBwd {
+    const bf16_t* dy;                       // [M,C] gradient of the block output
+    const bf16_t* xd;                       // [M,C] depthwise output (saved)
+    const float* ln_w; const float* ln_b; float eps;
+    const bf16_t* wt;                       // packed backward chunks
+    const float* b1;
+    bf16_t* dh; bf16_t* g;                  // [M,4C]
+    bf16_t* xln; bf16_t* dxln;              // [M,C] LN output (operand of dW1), gradient w.r.t. the LN output
+    float* mean; float* rstd;               // [M] for the LayerNorm backward
+    long M; int ntiles;
+};
+
+template <int C>
+__global__ __launch_bounds__(MLP_THREADS, 2) void cnblock_mlp_bwd_kernel(const MlpBwd p) {
+    constexpr int NC = MlpCfg<C>::NC;
+    constexpr int KS1 = C / 32, CT = C / 16, NSUB = NC / 32, NCH = 4 * C / NC;
+    constexpr int PART = NC * C * 2, CHUNK = 3 * PART, LOADS = CHUNK / 16 / MLP_THREADS;
+    static_assert(CHUNK % (16 * MLP_THREADS) == 0, "chunk must be a whole number of 16-byte granules per thread");
+    static_assert(NCH % 2 == 0, "ring parity is carried across tiles");
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_lnw = reinterpret_cast<float*>(smem + 2 * CHUNK);   // [C] [C] [4C]
+    float* s_lnb = s_lnw + C;
+    float* s_b1 = s_lnb + C;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lg = lane >> 4;
+    char* lds_wave = smem + (tid & ~63) * 16;
+    const char* wsrc = reinterpret_cast<const char*>(p.wt) + tid * 16;
+    auto stage = [&](int buf, int ch) {
+        const char* s = wsrc + (size_t)ch * CHUNK;
+#pragma unroll
+        for (int it = 0; it < LOADS; ++it) mlp_glds16(s + it * (MLP_THREADS * 16), lds_wave + buf * CHUNK + it * (MLP_THREADS * 16));
+    };
+    if ((int)blockIdx.x < p.ntiles) stage(0, 0);
+    for (int i = tid; i < C; i += MLP_THREADS) { s_lnw[i] = p.ln_w[i]; s_lnb[i] = p.ln_b[i]; }
+    for (int i = tid; i < 4 * C; i += MLP_THREADS) s_b1[i] = p.b1[i];
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const long row0 = (long)tile * MLP_BM + wave * 32 + li;
+        bf16x8 xf[2][KS1], dyf[2][KS1];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const long row = row0 + 16 * mi;
+            const long rr = row < p.M ? row : p.M - 1;
+            uint4 raw[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                raw[ks] = *reinterpret_cast<const uint4*>(p.xd + rr * C + 32 * ks + 8 * lg);
+                const uint4 dv = *reinterpret_cast<const uint4*>(p.dy + rr * C + 32 * ks + 8 * lg);
+                dyf[mi][ks] = __builtin_bit_cast(bf16x8, (u32x4_t{dv.x, dv.y, dv.z, dv.w}));
+            }
+            float v[KS1][8];
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const unsigned w[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[ks][2 * e] = bf2f_lo(w[e]); v[ks][2 * e + 1] = bf2f_hi(w[e]);
+                    s += v[ks][2 * e] + v[ks][2 * e + 1];
+                }
+            }
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            const float mean = s * (1.0f / C);
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mean; q = fmaf(d, d, q); }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q * (1.0f / C) + p.eps);
+            if (lg == 0 && row < p.M) { p.mean[row] = mean; p.rstd[row] = rstd; }
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_lnw + 32 * ks + 8 * lg);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_lnw + 32 * ks + 8 * lg + 4);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(s_lnb + 32 * ks + 8 * lg);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(s_lnb + 32 * ks + 8 * lg + 4);
+                const float g[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                const float b[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                unsigned o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack2bf(fmaf((v[ks][2 * e] - mean) * rstd, g[2 * e], b[2 * e]),
+                                   fmaf((v[ks][2 * e + 1] - mean) * rstd, g[2 * e + 1], b[2 * e + 1]));
+                xf[mi][ks] = __builtin_bit_cast(bf16x8, (u32x4_t{o[0], o[1], o[2], o[3]}));
+                if (row < p.M) *reinterpret_cast<uint4*>(p.xln + row * C + 32 * ks + 8 * lg) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+
+        f32x4 dxacc[2][CT];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dxacc[mi][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int ch = 0; ch < NCH; ++ch) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ch + 1 < NCH) stage((ch + 1) & 1, ch + 1);
+            else if (tile + (int)gridDim.x < p.ntiles) stage(0, 0);
+            const char* wb = smem + (ch & 1) * CHUNK;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int n0 = ch * NC + sub * 32 + 4 * lg;
+                const f32x4 bia0 = *reinterpret_cast<const f32x4*>(s_b1 + n0);
+                const f32x4 bia1 = *reinterpret_cast<const f32x4*>(s_b1 + n0 + 16);
+                f32x4 hacc[2][2], gacc[2][2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    hacc[mi][0] = bia0; hacc[mi][1] = bia1;
+                    gacc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; gacc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int off = ((4 * ks + lg) * NC + (2 * sub + tt) * 16 + li) << 4;
+                        const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(wb + off);
+                        const bf16x8 w2f = *reinterpret_cast<const bf16x8*>(wb + PART + off);
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) {
+                            hacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, xf[mi][ks], hacc[mi][tt], 0, 0, 0);
+                            gacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f, dyf[mi][ks], gacc[mi][tt], 0, 0, 0);
+                        }
+                    }
+                }
+                bf16x8 dhf[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    unsigned gp[4], dp[4];
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        float a[4], d[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float dg;
+                            gelu_both(hacc[mi][tt][e], a[e], dg);
+                            d[e] = gacc[mi][tt][e] * dg;
+                        }
+                        gp[2 * tt] = pack2bf(a[0], a[1]); gp[2 * tt + 1] = pack2bf(a[2], a[3]);
+                        dp[2 * tt] = pack2bf(d[0], d[1]); dp[2 * tt + 1] = pack2bf(d[2], d[3]);
+                    }
+                    dhf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{dp[0], dp[1], dp[2], dp[3]}));
+                    const long row = row0 + 16 * mi;
+                    if (row < p.M) {
+                        bf16_t* gq = p.g + row * (4 * C) + n0;
+                        bf16_t* dq = p.dh + row * (4 * C) + n0;
+                        *reinterpret_cast<uint2*>(gq) = make_uint2(gp[0], gp[1]);
+                        *reinterpret_cast<uint2*>(gq + 16) = make_uint2(gp[2], gp[3]);
+                        *reinterpret_cast<uint2*>(dq) = make_uint2(dp[0], dp[1]);
+                        *reinterpret_cast<uint2*>(dq + 16) = make_uint2(dp[2], dp[3]);
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + 2 * PART + (((4 * sub + lg) * C + ct * 16 + li) << 4));
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        dxacc[mi][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, dhf[mi], dxacc[mi][ct], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const long row = row0 + 16 * mi;
+            if (row < p.M) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f32x4 a = dxacc[mi][ct];
+                    *reinterpret_cast<uint2*>(p.dxln + row * C + ct * 16 + 4 * lg) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+                }
+            }
+        }
+    }
+}
+
+template <int C>
+static int launch_mlp_bwd(const MlpBwd& p, hipStream_t stream) {
+    constexpr int NC = MlpCfg<C>::NC;
+    const size_t lds = 2 * (3 * NC * C * 2) + (size_t)6 * C * sizeof(float);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t pr;
+        (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    const int grid = p.ntiles < 2 * cus ? p.ntiles : 2 * cus;
+    mmg_allow_lds(cnblock_mlp_bwd_kernel<C>, lds);
+    hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C>), dim3(grid), dim3(MLP_THREADS), lds, stream, p);
+    MMG_LAUNCH_CHECK("mmg_cnblock_mlp_bwd");
+    return 0;
+}
+
 template <int C>
 static int launch_mlp_fwd(const MlpFwd& p, hipStream_t stream) {
     constexpr int NC = MlpCfg<C>::NC;
@@ -309,4 +510,18 @@ MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* 
         case 192: return launch_mlp_fwd<192>(p, stream);
         default: return launch_mlp_fwd<256>(p, stream);
     }
+}
+
+MMG_API int mmg_cnblock_mlp_bwd_supported(int C) { return (C == 96 || C == 128) ? 1 : 0; }
+
+MMG_API int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps,
+                                const void* packed_bwd, const float* b1, void* dh, void* g, void* xln, void* dxln,
+                                float* mean, float* rstd, long long M, int C, hipStream_t stream) {
+    MMG_CHECK_ARG(dy && xd && ln_w && ln_b && packed_bwd && b1 && dh && g && xln && dxln && mean && rstd,
+                  "mmg_cnblock_mlp_bwd: null pointer");
+    MMG_CHECK_ARG(mmg_cnblock_mlp_bwd_supported(C), "mmg_cnblock_mlp_bwd: C=%d not in {96,128}", C);
+    MMG_CHECK_ARG(M > 0 && M < (1LL << 31) * MLP_BM, "mmg_cnblock_mlp_bwd: bad M=%lld", M);
+    MlpBwd p{(const bf16_t*)dy, (const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed_bwd, b1, (bf16_t*)dh, (bf16_t*)g,
+             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (long)M, (int)((M + MLP_BM - 1) / MLP_BM)};
+    return C == 96 ? launch_mlp_bwd<96>(p, stream) : launch_mlp_bwd<128>(p, stream);
 }

@@ -123,6 +123,24 @@ def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_h
     return y, hpre, mean, rstd
 
 
+def cnblock_bwd_supported(C):
+    return bool(_hip.load().mmg_cnblock_mlp_bwd_supported(C))
+
+
+def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1):
+    """-> dh, g [M,4C]; xln, dxln [M,C]; mean, rstd [M]  (see include/mmgclip_hip.h)."""
+    M, C = xd.shape
+    dev = xd.device
+    dh = torch.empty(M, 4 * C, device=dev, dtype=BF16)
+    g = torch.empty(M, 4 * C, device=dev, dtype=BF16)
+    xln, dxln = torch.empty_like(xd), torch.empty_like(xd)
+    mean = torch.empty(M, device=dev, dtype=torch.float32)
+    rstd = torch.empty(M, device=dev, dtype=torch.float32)
+    call("mmg_cnblock_mlp_bwd", ptr(dy), ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed_bwd), ptr(b1), ptr(dh), ptr(g),
+         ptr(xln), ptr(dxln), ptr(mean), ptr(rstd), M, C, stream())
+    return dh, g, xln, dxln, mean, rstd
+
+
 def attention_fwd(qkv, mask, B, S, heads, want_lse=True, force_long=False):
     """Whole-sequence-in-LDS kernel up to S = 512, flash-style tiled kernel beyond (or when force_long)."""
     Hd = heads * 64

@@ -133,6 +133,9 @@ class ConvNextTower(nn.Module):
                                                           blk.layer_scale.data.reshape(C))
                 if self.fused_mlp and K.cnblock_supported(C):                                # packed LDS images
                     wc[key + ".mlp"] = K.cnblock_pack(blk.block[3].weight.data, blk.block[5].weight.data)
+                    if K.cnblock_bwd_supported(C):
+                        wc[key + ".mlpb"] = K.cnblock_pack(blk.block[3].weight.data, blk.block[5].weight.data,
+                                                           blk.layer_scale.data.reshape(C), backward=True)
             if si < 3:
                 conv = f[2 + 2 * si][1].weight.data                                          # [2C, C, 2, 2]
                 wds = conv.permute(0, 2, 3, 1).reshape(conv.shape[0], -1).contiguous()       # [(kh,kw,ci)]
@@ -157,9 +160,10 @@ class ConvNextTower(nn.Module):
                 key = f"{si}.{bi}"
                 d = K.dwconv7(x, wc[key + ".w49"], blk.block[0].bias.data, n, h, w_, C)
                 if key + ".mlp" in wc:          # LN + Linear + GELU + Linear + layer scale + residual in one launch
+                    keep = save and key + ".mlpb" not in wc      # the fused backward recomputes the hidden row
                     xn, hpre, mean, rstd = K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS,
                                                              wc[key + ".mlp"], blk.block[3].bias.data, blk.block[5].bias.data,
-                                                             blk.layer_scale.data.reshape(C), x, want_hpre=save, want_stats=save)
+                                                             blk.layer_scale.data.reshape(C), x, want_hpre=keep, want_stats=keep)
                     if save:
                         saved[key] = (x, d, mean, rstd, hpre)
                     x = xn
@@ -206,15 +210,23 @@ class ConvNextTower(nn.Module):
                 blk = f[1 + 2 * si][bi]
                 key = f"{si}.{bi}"
                 x, d, mean, rstd, hpre = saved[key]
-                g = torch.empty_like(hpre)                 # GELU(hpre), rebuilt by the same epilogue that applies GELU'
-                dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
-                L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
-                del g
-                ln, _, _ = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=False)
-                L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
-                del ln
-                dln = L.gemm_nt(dh, wc[key + ".w1t"])
-                del dh
+                if hpre is None:                           # fused data path: hidden row recomputed on chip
+                    dh, g, ln, dln, mean, rstd = K.cnblock_mlp_bwd(dx, d, blk.block[2].weight.data, blk.block[2].bias.data,
+                                                                   LN_EPS, wc[key + ".mlpb"], blk.block[3].bias.data)
+                    L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
+                    del g
+                    L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
+                    del ln, dh
+                else:
+                    g = torch.empty_like(hpre)             # GELU(hpre), rebuilt by the same epilogue that applies GELU'
+                    dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
+                    L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
+                    del g
+                    ln, _, _ = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=False)
+                    L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
+                    del ln
+                    dln = L.gemm_nt(dh, wc[key + ".w1t"])
+                    del dh
                 dd = K.layernorm_bwd(dln, d, mean, rstd, blk.block[2].weight.data, gname(blk.block[2], "weight"),
                                      gname(blk.block[2], "bias"))
                 del dln

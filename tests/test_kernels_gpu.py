@@ -251,3 +251,34 @@ def test_fused_cnblock_mlp_forward_matches_unfused_reference(dev, C, M):
     assert torch.allclose(rstd.cpu(), (xd.float().var(1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-4)
     y2, _, _, _ = K.cnblock_mlp_fwd(d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1), d(b2), d(gamma), d(res))
     assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("C,M", [(96, 128 * 3 + 50), (128, 200)])
+def test_fused_cnblock_mlp_backward_data_path(dev, C, M):
+    """mmg_cnblock_mlp_bwd vs fp32 torch autograd of the same MLP: g, dh (operands of the weight-gradient GEMMs), LN output,
+    gradient w.r.t. the LN output and the LN statistics."""
+    from mmgclip import kernels as K
+    g_ = torch.Generator().manual_seed(7 * C + M)
+    xd = torch.randn(M, C, generator=g_).to(torch.bfloat16)
+    dy = (0.5 * torch.randn(M, C, generator=g_)).to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * torch.randn(C, generator=g_), 0.1 * torch.randn(C, generator=g_)
+    w1, b1 = torch.randn(4 * C, C, generator=g_) / C ** 0.5, 0.1 * torch.randn(4 * C, generator=g_)
+    w2 = torch.randn(C, 4 * C, generator=g_) / (4 * C) ** 0.5
+    gamma = 0.3 + 0.7 * torch.rand(C, generator=g_)
+    w1b, w2g = w1.to(torch.bfloat16).float(), (w2 * gamma[:, None]).to(torch.bfloat16).float()
+    ln = F.layer_norm(xd.float(), (C,), lnw, lnb, 1e-6).to(torch.bfloat16).float().requires_grad_(True)
+    h = ln @ w1b.t() + b1
+    gl = F.gelu(h)
+    dG = dy.float() @ w2g                                     # gradient w.r.t. GELU output (gamma folded like the kernel)
+    (dh_want,) = torch.autograd.grad(gl, h, dG, retain_graph=True)
+    dln_want = dh_want.to(torch.bfloat16).float() @ w1b
+    d = lambda t: t.to(dev)   # noqa: E731
+    packed = K.cnblock_pack(d(w1), d(w2), d(gamma), backward=True)
+    dh, gg, xln, dxln, mean, rstd = K.cnblock_mlp_bwd(d(dy), d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1))
+    torch.cuda.synchronize()
+    _close(xln, ln.detach(), 1e-2, 1e-2)
+    _close(gg, gl.detach(), 2e-2, 2e-2)
+    _close(dh, dh_want, 2e-2, 2e-2)
+    _close(dxln, dln_want, 2e-2, 3e-2)
+    _close(mean, xd.float().mean(1), 1e-5, 1e-5)
+    _close(rstd, (xd.float().var(1, unbiased=False) + 1e-6).rsqrt(), 1e-4, 1e-5)
