@@ -172,7 +172,7 @@ int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, const voi
 int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int H, int W, int C,
                       mmg_stream_t stream);
 
-/* ---- fused ConvNeXt block MLP (C in {96,128,192,256}) ---------------------------------------------------------- */
+/* ---- fused ConvNeXt block MLP (C in {96,128,192,256,384}) ---------------------------------------------------------- */
 
 /* Number of bf16 elements of the packed weight image (8C^2 forward, 12C^2 backward); 0 when C is unsupported. */
 long long mmg_cnblock_packed_elems(int C, int backward);
@@ -188,7 +188,7 @@ int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, fl
                         const float* b1, const float* b2, const float* gamma, const void* residual, void* y, void* hpre,
                         float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
 
-/* Data path of the CNBlock MLP backward in one launch (C in {96,128}; mmg_cnblock_mlp_bwd_supported tells): recomputes
+/* Data path of the CNBlock MLP backward in one launch (C in {96,128,192}; mmg_cnblock_mlp_bwd_supported tells): recomputes
  * h = LN(xd) W1^T + b1 from the saved depthwise output, and writes g = GELU(h), dh = (dy gamma W2) * GELU'(h) (bf16 [M,4C],
  * the operands of the weight-gradient GEMMs dW2 = dy^T g, dW1 = dh^T xln), xln = LN(xd) and dxln = dh W1 (bf16 [M,C]) plus the
  * LN statistics for mmg_layernorm_bwd.  packed_bwd = mmg_cnblock_pack_weights(..., backward=1).  The forward then saves

@@ -19,8 +19,6 @@
 // The bound is the fp32 VALU (erf-GELU, ~18 ops per hidden element = 3x the MFMA time at C=96), then HBM.
 #include "common.h"
 
-#define MLP_THREADS 256
-#define MLP_BM 128
 
 struct MlpFwd {
     const bf16_t* xd;                       // [M,C] depthwise output
@@ -39,9 +37,17 @@ __device__ __forceinline__ void mlp_glds16(const void* gsrc, void* lds_wave_base
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Work split per width.  Up to C = 256 a wave owns 32 rows (two 16-row MFMA tiles share every weight fragment read); at C = 384
+// the per-row state (C/4 operand + C/4 accumulator registers per tile) only leaves room for one tile per wave, so the
+// workgroup is 8 waves of 16 rows (one workgroup per CU) and the kernel is LDS-read bound (one fragment read per MFMA).
 template <int C> struct MlpCfg {
-    static constexpr int NC = (C <= 128) ? 64 : 32;
-    static constexpr int WGS = (C <= 96) ? 3 : (C <= 192 ? 2 : 1);     // workgroups per CU the registers / LDS allow
+    static constexpr int NC = (C <= 128) ? 64 : 32;                     // hidden columns per streamed chunk
+    static constexpr int MT = (C <= 256) ? 2 : 1;                       // 16-row tiles per wave
+    static constexpr int WAVES = (C <= 256) ? 4 : 8;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int BM = WAVES * 16 * MT;                          // rows per workgroup tile
+    static constexpr int WGS = (C <= 96) ? 3 : (C <= 192 ? 2 : 1);      // forward workgroups per CU (registers / LDS)
+    static constexpr int WGS_BWD = (C <= 192) ? 2 : 1;
 };
 
 // ---- weight packing --------------------------------------------------------------------------------------------------
@@ -82,8 +88,8 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const PackArgs a) {
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
 template <int C, bool SAVE>
-__global__ __launch_bounds__(MLP_THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_kernel(const MlpFwd p) {
-    constexpr int NC = MlpCfg<C>::NC;
+__global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_kernel(const MlpFwd p) {
+    constexpr int NC = MlpCfg<C>::NC, MT = MlpCfg<C>::MT, MLP_THREADS = MlpCfg<C>::THREADS, MLP_BM = MlpCfg<C>::BM;
     constexpr int KS1 = C / 32, CT = C / 16, NSUB = NC / 32, NCH = 4 * C / NC;
     constexpr int PART = NC * C * 2, CHUNK = 2 * PART, LOADS = CHUNK / 16 / MLP_THREADS;
     static_assert(CHUNK % (16 * MLP_THREADS) == 0, "chunk must be a whole number of 16-byte granules per thread");
@@ -113,11 +119,11 @@ __global__ __launch_bounds__(MLP_THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_k
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const long row0 = (long)tile * MLP_BM + wave * 32 + li;          // + 16*mi
+        const long row0 = (long)tile * MLP_BM + wave * (16 * MT) + li;          // + 16*mi
         // ---- rows of d -> LayerNorm -> bf16 B-operand fragments ---------------------------------------------------------
-        bf16x8 xf[2][KS1];
+        bf16x8 xf[MT][KS1];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
             const long rr = row < p.M ? row : p.M - 1;
             uint4 raw[KS1];
@@ -162,9 +168,9 @@ __global__ __launch_bounds__(MLP_THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_k
             }
         }
 
-        f32x4 yacc[2][CT];
+        f32x4 yacc[MT][CT];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) yacc[mi][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -181,22 +187,22 @@ __global__ __launch_bounds__(MLP_THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_k
                 const int n0 = ch * NC + sub * 32 + 4 * lg;
                 const f32x4 bia0 = *reinterpret_cast<const f32x4*>(s_b1 + n0);
                 const f32x4 bia1 = *reinterpret_cast<const f32x4*>(s_b1 + n0 + 16);
-                f32x4 hacc[2][2];
+                f32x4 hacc[MT][2];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) { hacc[mi][0] = bia0; hacc[mi][1] = bia1; }
+                for (int mi = 0; mi < MT; ++mi) { hacc[mi][0] = bia0; hacc[mi][1] = bia1; }
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks) {
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + (((4 * ks + lg) * NC + (2 * sub + tt) * 16 + li) << 4));
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
+                        for (int mi = 0; mi < MT; ++mi)
                             hacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mi][ks], hacc[mi][tt], 0, 0, 0);
                     }
                 }
-                bf16x8 gf[2];
+                bf16x8 gf[MT];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
+                for (int mi = 0; mi < MT; ++mi) {
                     const f32x4 h0 = hacc[mi][0], h1 = hacc[mi][1];
                     if (SAVE) {
                         const long row = row0 + 16 * mi;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(MLP_THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_k
                 for (int ct = 0; ct < CT; ++ct) {
                     const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + PART + (((4 * sub + lg) * C + ct * 16 + li) << 4));
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MT; ++mi)
                         yacc[mi][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf[mi], yacc[mi][ct], 0, 0, 0);
                 }
             }
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(MLP_THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_k
 
         // ---- y = x + gamma * (acc + b2) -----------------------------------------------------------------------------------
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
             if (row < p.M) {
                 uint2 rv[CT];
@@ -260,8 +266,8 @@ struct MlpBwd {
 };
 
 template <int C>
-__global__ __launch_bounds__(MLP_THREADS, 2) void cnblock_mlp_bwd_kernel(const MlpBwd p) {
-    constexpr int NC = MlpCfg<C>::NC;
+__global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnblock_mlp_bwd_kernel(const MlpBwd p) {
+    constexpr int NC = MlpCfg<C>::NC, MT = MlpCfg<C>::MT, MLP_THREADS = MlpCfg<C>::THREADS, MLP_BM = MlpCfg<C>::BM;
     constexpr int KS1 = C / 32, CT = C / 16, NSUB = NC / 32, NCH = 4 * C / NC;
     constexpr int PART = NC * C * 2, CHUNK = 3 * PART, LOADS = CHUNK / 16 / MLP_THREADS;
     static_assert(CHUNK % (16 * MLP_THREADS) == 0, "chunk must be a whole number of 16-byte granules per thread");
@@ -287,10 +293,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void cnblock_mlp_bwd_kernel(const M
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const long row0 = (long)tile * MLP_BM + wave * 32 + li;
-        bf16x8 xf[2][KS1], dyf[2][KS1];
+        const long row0 = (long)tile * MLP_BM + wave * (16 * MT) + li;
+        bf16x8 xf[MT][KS1], dyf[MT][KS1];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
             const long rr = row < p.M ? row : p.M - 1;
             uint4 raw[KS1];
@@ -339,9 +345,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void cnblock_mlp_bwd_kernel(const M
             }
         }
 
-        f32x4 dxacc[2][CT];
+        f32x4 dxacc[MT][CT];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) dxacc[mi][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -356,9 +362,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void cnblock_mlp_bwd_kernel(const M
                 const int n0 = ch * NC + sub * 32 + 4 * lg;
                 const f32x4 bia0 = *reinterpret_cast<const f32x4*>(s_b1 + n0);
                 const f32x4 bia1 = *reinterpret_cast<const f32x4*>(s_b1 + n0 + 16);
-                f32x4 hacc[2][2], gacc[2][2];
+                f32x4 hacc[MT][2], gacc[MT][2];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
+                for (int mi = 0; mi < MT; ++mi) {
                     hacc[mi][0] = bia0; hacc[mi][1] = bia1;
                     gacc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; gacc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -370,15 +376,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void cnblock_mlp_bwd_kernel(const M
                         const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(wb + off);
                         const bf16x8 w2f = *reinterpret_cast<const bf16x8*>(wb + PART + off);
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi) {
+                        for (int mi = 0; mi < MT; ++mi) {
                             hacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, xf[mi][ks], hacc[mi][tt], 0, 0, 0);
                             gacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f, dyf[mi][ks], gacc[mi][tt], 0, 0, 0);
                         }
                     }
                 }
-                bf16x8 dhf[2];
+                bf16x8 dhf[MT];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
+                for (int mi = 0; mi < MT; ++mi) {
                     unsigned gp[4], dp[4];
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
@@ -407,13 +413,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void cnblock_mlp_bwd_kernel(const M
                 for (int ct = 0; ct < CT; ++ct) {
                     const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + 2 * PART + (((4 * sub + lg) * C + ct * 16 + li) << 4));
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MT; ++mi)
                         dxacc[mi][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, dhf[mi], dxacc[mi][ct], 0, 0, 0);
                 }
             }
         }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
             if (row < p.M) {
 #pragma unroll
@@ -426,47 +432,48 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void cnblock_mlp_bwd_kernel(const M
     }
 }
 
-template <int C>
-static int launch_mlp_bwd(const MlpBwd& p, hipStream_t stream) {
-    constexpr int NC = MlpCfg<C>::NC;
-    const size_t lds = 2 * (3 * NC * C * 2) + (size_t)6 * C * sizeof(float);
+static int mlp_cu_count() {
     static int cus = 0;
     if (!cus) {
         int dev = 0; hipDeviceProp_t pr;
         (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
         cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }
-    const int grid = p.ntiles < 2 * cus ? p.ntiles : 2 * cus;
+    return cus;
+}
+
+template <int C>
+static int launch_mlp_bwd(MlpBwd p, hipStream_t stream) {
+    typedef MlpCfg<C> Cfg;
+    const size_t lds = 2 * (3 * Cfg::NC * C * 2) + (size_t)6 * C * sizeof(float);
+    p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
+    const int cap = Cfg::WGS_BWD * mlp_cu_count();
+    const int grid = p.ntiles < cap ? p.ntiles : cap;
     mmg_allow_lds(cnblock_mlp_bwd_kernel<C>, lds);
-    hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C>), dim3(grid), dim3(MLP_THREADS), lds, stream, p);
+    hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
     MMG_LAUNCH_CHECK("mmg_cnblock_mlp_bwd");
     return 0;
 }
 
 template <int C>
-static int launch_mlp_fwd(const MlpFwd& p, hipStream_t stream) {
-    constexpr int NC = MlpCfg<C>::NC;
-    const size_t lds = 2 * (2 * NC * C * 2) + (size_t)8 * C * sizeof(float);
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t pr;
-        (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    }
-    const int per_cu = MlpCfg<C>::WGS;
-    const int grid = p.ntiles < per_cu * cus ? p.ntiles : per_cu * cus;
+static int launch_mlp_fwd(MlpFwd p, hipStream_t stream) {
+    typedef MlpCfg<C> Cfg;
+    const size_t lds = 2 * (2 * Cfg::NC * C * 2) + (size_t)8 * C * sizeof(float);
+    p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
+    const int cap = Cfg::WGS * mlp_cu_count();
+    const int grid = p.ntiles < cap ? p.ntiles : cap;
     if (p.hpre) {
         mmg_allow_lds(cnblock_mlp_fwd_kernel<C, true>, lds);
-        hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, true>), dim3(grid), dim3(MLP_THREADS), lds, stream, p);
+        hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, true>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
     } else {
         mmg_allow_lds(cnblock_mlp_fwd_kernel<C, false>, lds);
-        hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, false>), dim3(grid), dim3(MLP_THREADS), lds, stream, p);
+        hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, false>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
     }
     MMG_LAUNCH_CHECK("mmg_cnblock_mlp_fwd");
     return 0;
 }
 
-static bool mlp_supported(int C) { return C == 96 || C == 128 || C == 192 || C == 256; }
+static bool mlp_supported(int C) { return C == 96 || C == 128 || C == 192 || C == 256 || C == 384; }
 
 MMG_API long long mmg_cnblock_packed_elems(int C, int backward) {
     if (!mlp_supported(C)) return 0;
@@ -476,10 +483,10 @@ MMG_API long long mmg_cnblock_packed_elems(int C, int backward) {
 MMG_API int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamma, void* packed, int C, int backward,
                                      hipStream_t stream) {
     MMG_CHECK_ARG(w1 && w2 && packed, "mmg_cnblock_pack_weights: null pointer");
-    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_pack_weights: C=%d not in {96,128,192,256}", C);
+    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_pack_weights: C=%d not in {96,128,192,256,384}", C);
     MMG_CHECK_ARG(!backward || gamma, "mmg_cnblock_pack_weights: the backward image needs the layer scale");
     PackArgs a{};
-    a.out = (bf16_t*)packed; a.C = C; a.NC = C <= 128 ? 64 : 32;
+    a.out = (bf16_t*)packed; a.C = C; a.NC = C <= 128 ? 64 : 32;      // = MlpCfg<C>::NC
     a.part[0] = PackPart{w1, 0, nullptr, 0};                       // W1 rows n, K = c            (hidden = x W1^T)
     if (!backward) {
         a.parts = 2;
@@ -498,30 +505,36 @@ MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* 
                                 const float* b1, const float* b2, const float* gamma, const void* residual, void* y,
                                 void* hpre, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
     MMG_CHECK_ARG(xd && ln_w && ln_b && packed && b1 && b2 && gamma && residual && y, "mmg_cnblock_mlp_fwd: null pointer");
-    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_mlp_fwd: C=%d not in {96,128,192,256}", C);
-    MMG_CHECK_ARG(M > 0 && M < (1L << 31) * MLP_BM, "mmg_cnblock_mlp_fwd: bad M=%lld", M);
+    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_mlp_fwd: C=%d not in {96,128,192,256,384}", C);
+    MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_fwd: bad M=%lld", M);
     MMG_CHECK_ARG((mean == nullptr) == (hpre == nullptr) && (rstd == nullptr) == (hpre == nullptr),
                   "mmg_cnblock_mlp_fwd: hpre, mean and rstd are saved together or not at all");
     MlpFwd p{(const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed, b1, b2, gamma, (const bf16_t*)residual, (bf16_t*)y,
-             (bf16_t*)hpre, mean, rstd, (long)M, (int)((M + MLP_BM - 1) / MLP_BM)};
+             (bf16_t*)hpre, mean, rstd, (long)M, 0};
     switch (C) {
         case 96: return launch_mlp_fwd<96>(p, stream);
         case 128: return launch_mlp_fwd<128>(p, stream);
         case 192: return launch_mlp_fwd<192>(p, stream);
-        default: return launch_mlp_fwd<256>(p, stream);
+        case 256: return launch_mlp_fwd<256>(p, stream);
+        default: return launch_mlp_fwd<384>(p, stream);
     }
 }
 
-MMG_API int mmg_cnblock_mlp_bwd_supported(int C) { return (C == 96 || C == 128) ? 1 : 0; }
+// (C = 384 builds and is correct, but one 16-row tile per wave makes it LDS-read bound and slower than the GEMM pair)
+MMG_API int mmg_cnblock_mlp_bwd_supported(int C) { return (C == 96 || C == 128 || C == 192) ? 1 : 0; }
 
 MMG_API int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps,
                                 const void* packed_bwd, const float* b1, void* dh, void* g, void* xln, void* dxln,
                                 float* mean, float* rstd, long long M, int C, hipStream_t stream) {
     MMG_CHECK_ARG(dy && xd && ln_w && ln_b && packed_bwd && b1 && dh && g && xln && dxln && mean && rstd,
                   "mmg_cnblock_mlp_bwd: null pointer");
-    MMG_CHECK_ARG(mmg_cnblock_mlp_bwd_supported(C), "mmg_cnblock_mlp_bwd: C=%d not in {96,128}", C);
-    MMG_CHECK_ARG(M > 0 && M < (1LL << 31) * MLP_BM, "mmg_cnblock_mlp_bwd: bad M=%lld", M);
+    MMG_CHECK_ARG(mmg_cnblock_mlp_bwd_supported(C), "mmg_cnblock_mlp_bwd: C=%d not in {96,128,192}", C);
+    MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_bwd: bad M=%lld", M);
     MlpBwd p{(const bf16_t*)dy, (const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed_bwd, b1, (bf16_t*)dh, (bf16_t*)g,
-             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (long)M, (int)((M + MLP_BM - 1) / MLP_BM)};
-    return C == 96 ? launch_mlp_bwd<96>(p, stream) : launch_mlp_bwd<128>(p, stream);
+             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (long)M, 0};
+    switch (C) {
+        case 96: return launch_mlp_bwd<96>(p, stream);
+        case 128: return launch_mlp_bwd<128>(p, stream);
+        default: return launch_mlp_bwd<192>(p, stream);
+    }
 }

@@ -366,8 +366,10 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     const bool n96 = (N % 128 != 0) && (N % 96 == 0);
     // K < 384 (ConvNeXt stages 1-2, stem): HBM/latency bound -> 16 KiB stages, three of them, three workgroups per CU
     static const int use_3wg = getenv("MMG_GEMM_3WG") ? atoi(getenv("MMG_GEMM_3WG")) : 1;
-    if (use_3wg && !n96 && K % 32 == 0 && K < 384) launch_nt<128, 128, 32, 2, 3>(g, stream);
-    else if (use_big && k64 && !n96 && M >= 4096 && K >= 512) launch_nt<256, 128, 64, 4, 3>(g, stream);
+    static const int k3_max = getenv("MMG_GEMM_K3") ? atoi(getenv("MMG_GEMM_K3")) : 384;       // 3-WG config below this K
+    static const int kbig_min = getenv("MMG_GEMM_KBIG") ? atoi(getenv("MMG_GEMM_KBIG")) : 512;  // 256x128 config from this K
+    if (use_3wg && !n96 && K % 32 == 0 && K < k3_max) launch_nt<128, 128, 32, 2, 3>(g, stream);
+    else if (use_big && k64 && !n96 && M >= 4096 && K >= kbig_min) launch_nt<256, 128, 64, 4, 3>(g, stream);
     else if (n96) { if (k64) launch_nt<128, 96, 64, 2, 2>(g, stream); else launch_nt<128, 96, 32, 2, 2>(g, stream); }
     else          { if (k64) launch_nt<128, 128, 64, 2, 2>(g, stream); else launch_nt<128, 128, 32, 2, 2>(g, stream); }
     MMG_LAUNCH_CHECK("mmg_gemm_nt_bf16");

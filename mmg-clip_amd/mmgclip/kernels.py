@@ -97,7 +97,7 @@ def dwconv7_wgrad(x, dy, dw49, dbias, n, H, W, C):
 
 
 def cnblock_supported(C):
-    return C in (96, 128, 192, 256)
+    return C in (96, 128, 192, 256, 384)
 
 
 def cnblock_pack(w1, w2, gamma=None, backward=False):

@@ -224,7 +224,7 @@ def test_attention_long_fwd_bwd(dev, B, S, heads, masked):
         _close(lse, lse2, 1e-4, 1e-4)
 
 
-@pytest.mark.parametrize("C,M", [(96, 128 * 5 + 37), (192, 300), (128, 129), (256, 200)])
+@pytest.mark.parametrize("C,M", [(96, 128 * 5 + 37), (192, 300), (128, 129), (256, 200), (384, 128 * 2 + 19)])
 def test_fused_cnblock_mlp_forward_matches_unfused_reference(dev, C, M):
     """mmg_cnblock_mlp_fwd = LN -> Linear(C,4C) -> GELU -> Linear(4C,C) -> layer scale -> + residual in one launch
     (torchvision CNBlock.block[2..5]); fp32 torch of the same op on the same bf16 inputs / bf16-rounded weights."""
@@ -253,7 +253,7 @@ def test_fused_cnblock_mlp_forward_matches_unfused_reference(dev, C, M):
     assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("C,M", [(96, 128 * 3 + 50), (128, 200)])
+@pytest.mark.parametrize("C,M", [(96, 128 * 3 + 50), (128, 200), (192, 333)])
 def test_fused_cnblock_mlp_backward_data_path(dev, C, M):
     """mmg_cnblock_mlp_bwd vs fp32 torch autograd of the same MLP: g, dh (operands of the weight-gradient GEMMs), LN output,
     gradient w.r.t. the LN output and the LN statistics."""

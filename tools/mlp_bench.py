@@ -5,7 +5,7 @@ import torch
 from mmgclip import kernels as K, linalg as L
 
 dev = torch.device("cuda")
-for C, px, n in ((96, 256 * 256, 64), (192, 128 * 128, 64)):
+for C, px, n in ((96, 256 * 256, 64), (192, 128 * 128, 64), (384, 64 * 64, 64)):
     M = px * n
     g = torch.Generator().manual_seed(0)
     xd = torch.randn(M // 64, C, generator=g).to(torch.bfloat16).repeat(64, 1).to(dev)
@@ -26,7 +26,7 @@ for C, px, n in ((96, 256 * 256, 64), (192, 128 * 128, 64)):
         gg = L.gemm_nt(ln, w1b, bias=b1, epi=L.EPI_GELU, aux_out=hpre)
         return L.gemm_nt(gg, w2b, bias=b2, colscale=gamma, residual=res)
 
-    for name, fn in (("fused", lambda: fused(False)), ("fused+hpre", lambda: fused(True)), ("unfused", unfused)):
+    for name, fn in (("fused", lambda: fused(False)), ("fused+hpre", lambda: fused(True)), ("unfused", unfused), ("fused", lambda: fused(False))):
         fn(); fn(); fn(); torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(20):
