@@ -174,10 +174,10 @@ int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* dbias, in
 
 /* ---- fused ConvNeXt block MLP (C in {96,128,192,256,384}) ---------------------------------------------------------- */
 
-/* Number of bf16 elements of the packed weight image (8C^2 forward, 12C^2 backward); 0 when C is unsupported. */
+/* Number of bf16 elements of the packed weight image (8C^2 forward / backward=2, 12C^2 backward=1); 0 when C is unsupported. */
 long long mmg_cnblock_packed_elems(int C, int backward);
 /* Pack W1 fp32 [4C,C], W2 fp32 [C,4C] (torchvision CNBlock.block[3] / block[5]) into the per-chunk LDS images the fused
- * kernels stream (layout: csrc/cnblock_mlp.hip).  backward != 0 builds [W1 | gamma*W2^T | W1^T] and needs gamma [C]. */
+ * kernels stream (layout: csrc/cnblock_mlp.hip).  backward = 1 builds [W1 | gamma*W2^T | W1^T], backward = 2 builds [gamma*W2^T | W1^T]; both need gamma [C]. */
 int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamma, void* packed, int C, int backward,
                              mmg_stream_t stream);
 /* y = residual + gamma * ( GELU( LayerNorm(xd; ln_w, ln_b, eps) W1^T + b1 ) W2^T + b2 ), rows of [M,C] bf16.
@@ -188,15 +188,16 @@ int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, fl
                         const float* b1, const float* b2, const float* gamma, const void* residual, void* y, void* hpre,
                         float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
 
-/* Data path of the CNBlock MLP backward in one launch (C in {96,128,192}; mmg_cnblock_mlp_bwd_supported tells): recomputes
- * h = LN(xd) W1^T + b1 from the saved depthwise output, and writes g = GELU(h), dh = (dy gamma W2) * GELU'(h) (bf16 [M,4C],
- * the operands of the weight-gradient GEMMs dW2 = dy^T g, dW1 = dh^T xln), xln = LN(xd) and dxln = dh W1 (bf16 [M,C]) plus the
- * LN statistics for mmg_layernorm_bwd.  packed_bwd = mmg_cnblock_pack_weights(..., backward=1).  The forward then saves
- * nothing 4C-wide.  (New capability: the reference never trains the image tower, mmgclip/networks/encoder.py:53.) */
+/* Data path of the CNBlock MLP backward in one launch.  mmg_cnblock_mlp_bwd_supported(C): 1 (C in {96,128,192}) = the
+ * hidden row h = LN(xd) W1^T + b1 is recomputed from the saved depthwise output, packed_bwd = pack(..., backward=1), hpre must
+ * be NULL and the forward saves nothing 4C-wide; 2 (C = 384) = h is read back from the forward's hpre, packed_bwd =
+ * pack(..., backward=2); 0 = unsupported.  Writes g = GELU(h), dh = (dy gamma W2) * GELU'(h) (bf16 [M,4C], operands of the
+ * weight-gradient GEMMs dW2 = dy^T g, dW1 = dh^T xln), xln = LN(xd) and dxln = dh W1 (bf16 [M,C]) and the LN statistics for
+ * mmg_layernorm_bwd.  (New capability: the reference never trains the image tower, mmgclip/networks/encoder.py:53.) */
 int mmg_cnblock_mlp_bwd_supported(int C);
 int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps,
-                        const void* packed_bwd, const float* b1, void* dh, void* g, void* xln, void* dxln, float* mean,
-                        float* rstd, long long M, int C, mmg_stream_t stream);
+                        const void* packed_bwd, const float* b1, const void* hpre, void* dh, void* g, void* xln,
+                        void* dxln, float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
 
 /* ---- BERT attention / embeddings / pooling -------------------------------------------------------------------- */
 

@@ -262,14 +262,19 @@ struct MlpBwd {
     bf16_t* dh; bf16_t* g;                  // [M,4C]
     bf16_t* xln; bf16_t* dxln;              // [M,C] LN output (operand of dW1), gradient w.r.t. the LN output
     float* mean; float* rstd;               // [M] for the LayerNorm backward
+    const bf16_t* hpre;                     // [M,4C] saved pre-activation (RECOMP = false only)
     long M; int ntiles;
 };
 
-template <int C>
+// RECOMP = false (C = 384): the pre-activation is read back from the forward's `hpre` instead of being recomputed, so the
+// W1 part, its MFMAs and the LN-output fragments drop out (one 16-row tile per wave cannot afford them: registers, and one
+// LDS fragment read per MFMA); chunks are then [gamma*W2^T | W1^T].
+template <int C, bool RECOMP>
 __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnblock_mlp_bwd_kernel(const MlpBwd p) {
     constexpr int NC = MlpCfg<C>::NC, MT = MlpCfg<C>::MT, MLP_THREADS = MlpCfg<C>::THREADS, MLP_BM = MlpCfg<C>::BM;
     constexpr int KS1 = C / 32, CT = C / 16, NSUB = NC / 32, NCH = 4 * C / NC;
-    constexpr int PART = NC * C * 2, CHUNK = 3 * PART, LOADS = CHUNK / 16 / MLP_THREADS;
+    constexpr int NPART = RECOMP ? 3 : 2, P_W2 = RECOMP ? 1 : 0, P_W1T = RECOMP ? 2 : 1;
+    constexpr int PART = NC * C * 2, CHUNK = NPART * PART, LOADS = CHUNK / 16 / MLP_THREADS;
     static_assert(CHUNK % (16 * MLP_THREADS) == 0, "chunk must be a whole number of 16-byte granules per thread");
     static_assert(NCH % 2 == 0, "ring parity is carried across tiles");
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const long row0 = (long)tile * MLP_BM + wave * (16 * MT) + li;
-        bf16x8 xf[MT][KS1], dyf[MT][KS1];
+        bf16x8 xf[RECOMP ? MT : 1][RECOMP ? KS1 : 1], dyf[MT][KS1];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                 for (int e = 0; e < 4; ++e)
                     o[e] = pack2bf(fmaf((v[ks][2 * e] - mean) * rstd, g[2 * e], b[2 * e]),
                                    fmaf((v[ks][2 * e + 1] - mean) * rstd, g[2 * e + 1], b[2 * e + 1]));
-                xf[mi][ks] = __builtin_bit_cast(bf16x8, (u32x4_t{o[0], o[1], o[2], o[3]}));
+                if (RECOMP) xf[RECOMP ? mi : 0][RECOMP ? ks : 0] = __builtin_bit_cast(bf16x8, (u32x4_t{o[0], o[1], o[2], o[3]}));
                 if (row < p.M) *reinterpret_cast<uint4*>(p.xln + row * C + 32 * ks + 8 * lg) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
@@ -365,7 +370,16 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                 f32x4 hacc[MT][2], gacc[MT][2];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
-                    hacc[mi][0] = bia0; hacc[mi][1] = bia1;
+                    if (RECOMP) {
+                        hacc[mi][0] = bia0; hacc[mi][1] = bia1;
+                    } else {             // saved pre-activation (bias already in it): lane = row, 4 consecutive columns
+                        const long row = row0 + 16 * mi;
+                        const long rr = row < p.M ? row : p.M - 1;
+                        const bf16_t* hq = p.hpre + rr * (4 * C) + n0;
+                        const uint2 u0 = *reinterpret_cast<const uint2*>(hq), u1 = *reinterpret_cast<const uint2*>(hq + 16);
+                        hacc[mi][0] = f32x4{bf2f_lo(u0.x), bf2f_hi(u0.x), bf2f_lo(u0.y), bf2f_hi(u0.y)};
+                        hacc[mi][1] = f32x4{bf2f_lo(u1.x), bf2f_hi(u1.x), bf2f_lo(u1.y), bf2f_hi(u1.y)};
+                    }
                     gacc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; gacc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
@@ -373,13 +387,16 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         const int off = ((4 * ks + lg) * NC + (2 * sub + tt) * 16 + li) << 4;
-                        const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(wb + off);
-                        const bf16x8 w2f = *reinterpret_cast<const bf16x8*>(wb + PART + off);
+                        const bf16x8 w2f = *reinterpret_cast<const bf16x8*>(wb + P_W2 * PART + off);
+                        if (RECOMP) {
+                            const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(wb + off);
 #pragma unroll
-                        for (int mi = 0; mi < MT; ++mi) {
-                            hacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, xf[mi][ks], hacc[mi][tt], 0, 0, 0);
-                            gacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f, dyf[mi][ks], gacc[mi][tt], 0, 0, 0);
+                            for (int mi = 0; mi < MT; ++mi)
+                                hacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f, xf[RECOMP ? mi : 0][RECOMP ? ks : 0], hacc[mi][tt], 0, 0, 0);
                         }
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+                            gacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f, dyf[mi][ks], gacc[mi][tt], 0, 0, 0);
                     }
                 }
                 bf16x8 dhf[MT];
@@ -411,7 +428,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + 2 * PART + (((4 * sub + lg) * C + ct * 16 + li) << 4));
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + P_W1T * PART + (((4 * sub + lg) * C + ct * 16 + li) << 4));
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi)
                         dxacc[mi][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, dhf[mi], dxacc[mi][ct], 0, 0, 0);
@@ -442,15 +459,15 @@ static int mlp_cu_count() {
     return cus;
 }
 
-template <int C>
+template <int C, bool RECOMP>
 static int launch_mlp_bwd(MlpBwd p, hipStream_t stream) {
     typedef MlpCfg<C> Cfg;
-    const size_t lds = 2 * (3 * Cfg::NC * C * 2) + (size_t)6 * C * sizeof(float);
+    const size_t lds = 2 * ((RECOMP ? 3 : 2) * Cfg::NC * C * 2) + (size_t)6 * C * sizeof(float);
     p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     const int cap = Cfg::WGS_BWD * mlp_cu_count();
     const int grid = p.ntiles < cap ? p.ntiles : cap;
-    mmg_allow_lds(cnblock_mlp_bwd_kernel<C>, lds);
-    hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
+    mmg_allow_lds(cnblock_mlp_bwd_kernel<C, RECOMP>, lds);
+    hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C, RECOMP>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
     MMG_LAUNCH_CHECK("mmg_cnblock_mlp_bwd");
     return 0;
 }
@@ -477,13 +494,14 @@ static bool mlp_supported(int C) { return C == 96 || C == 128 || C == 192 || C =
 
 MMG_API long long mmg_cnblock_packed_elems(int C, int backward) {
     if (!mlp_supported(C)) return 0;
-    return (long long)(backward ? 3 : 2) * 4 * C * C;
+    return (long long)(backward == 1 ? 3 : 2) * 4 * C * C;
 }
 
 MMG_API int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamma, void* packed, int C, int backward,
                                      hipStream_t stream) {
     MMG_CHECK_ARG(w1 && w2 && packed, "mmg_cnblock_pack_weights: null pointer");
     MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_pack_weights: C=%d not in {96,128,192,256,384}", C);
+    MMG_CHECK_ARG(backward >= 0 && backward <= 2, "mmg_cnblock_pack_weights: backward=%d not in {0,1,2}", backward);
     MMG_CHECK_ARG(!backward || gamma, "mmg_cnblock_pack_weights: the backward image needs the layer scale");
     PackArgs a{};
     a.out = (bf16_t*)packed; a.C = C; a.NC = C <= 128 ? 64 : 32;      // = MlpCfg<C>::NC
@@ -491,10 +509,14 @@ MMG_API int mmg_cnblock_pack_weights(const float* w1, const float* w2, const flo
     if (!backward) {
         a.parts = 2;
         a.part[1] = PackPart{w2, 1, nullptr, 1};                   // W2 rows c, K = n            (y = g W2^T)
-    } else {
+    } else if (backward == 1) {
         a.parts = 3;
         a.part[1] = PackPart{w2, 1, gamma, 0};                     // gamma*W2^T rows n, K = c    (dG = dy (gamma W2))
         a.part[2] = PackPart{w1, 0, nullptr, 1};                   // W1^T rows c, K = n          (dx = dH W1)
+    } else {                                                       // backward == 2: pre-activation read back, no W1 part
+        a.parts = 2;
+        a.part[0] = PackPart{w2, 1, gamma, 0};
+        a.part[1] = PackPart{w1, 0, nullptr, 1};
     }
     hipLaunchKernelGGL(mlp_pack_kernel, dim3(256), dim3(256), 0, stream, a);
     MMG_LAUNCH_CHECK("mmg_cnblock_pack_weights");
@@ -520,21 +542,24 @@ MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* 
     }
 }
 
-// (C = 384 builds and is correct, but one 16-row tile per wave makes it LDS-read bound and slower than the GEMM pair)
-MMG_API int mmg_cnblock_mlp_bwd_supported(int C) { return (C == 96 || C == 128 || C == 192) ? 1 : 0; }
+// 1: hidden row recomputed (forward saves nothing 4C-wide); 2: needs the forward's saved pre-activation `hpre`; 0: unsupported
+MMG_API int mmg_cnblock_mlp_bwd_supported(int C) { return (C == 96 || C == 128 || C == 192) ? 1 : (C == 384 ? 2 : 0); }
 
 MMG_API int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps,
-                                const void* packed_bwd, const float* b1, void* dh, void* g, void* xln, void* dxln,
-                                float* mean, float* rstd, long long M, int C, hipStream_t stream) {
+                                const void* packed_bwd, const float* b1, const void* hpre, void* dh, void* g, void* xln,
+                                void* dxln, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
     MMG_CHECK_ARG(dy && xd && ln_w && ln_b && packed_bwd && b1 && dh && g && xln && dxln && mean && rstd,
                   "mmg_cnblock_mlp_bwd: null pointer");
-    MMG_CHECK_ARG(mmg_cnblock_mlp_bwd_supported(C), "mmg_cnblock_mlp_bwd: C=%d not in {96,128,192}", C);
+    const int mode = mmg_cnblock_mlp_bwd_supported(C);
+    MMG_CHECK_ARG(mode != 0, "mmg_cnblock_mlp_bwd: C=%d not in {96,128,192,384}", C);
+    MMG_CHECK_ARG((mode == 2) == (hpre != nullptr), "mmg_cnblock_mlp_bwd: hpre is required for C=384 and unused otherwise (C=%d)", C);
     MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_bwd: bad M=%lld", M);
     MlpBwd p{(const bf16_t*)dy, (const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed_bwd, b1, (bf16_t*)dh, (bf16_t*)g,
-             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (long)M, 0};
+             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (const bf16_t*)hpre, (long)M, 0};
     switch (C) {
-        case 96: return launch_mlp_bwd<96>(p, stream);
-        case 128: return launch_mlp_bwd<128>(p, stream);
-        default: return launch_mlp_bwd<192>(p, stream);
+        case 96: return launch_mlp_bwd<96, true>(p, stream);
+        case 128: return launch_mlp_bwd<128, true>(p, stream);
+        case 192: return launch_mlp_bwd<192, true>(p, stream);
+        default: return launch_mlp_bwd<384, false>(p, stream);
     }
 }

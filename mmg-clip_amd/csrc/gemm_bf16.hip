@@ -169,7 +169,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int NST>
-__global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : 2) void gemm_nt_kernel(const GemmNT g) {
+__global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 128 ? 1 : 2)) void gemm_nt_kernel(const GemmNT g) {
     constexpr int THREADS = WAVES_M * 128;
     constexpr int MI = 4, NI = BN / 32;                  // 16x16 fragments per wave (wave tile 64 x BN/2)
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -285,10 +285,11 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : 2) void
 
     // issue EVERY global read of the epilogue (residual / saved pre-activation rows of all passes) before the
     // accumulators go through LDS, so their latency overlaps the staging instead of being paid pass by pass.
-    uint4 res_v[PASSES], aux_v[PASSES];
+    constexpr bool PREFETCH = PASSES <= 8;                // (wider tiles: 16 passes of prefetch would spill)
+    uint4 res_v[PREFETCH ? PASSES : 1], aux_v[PREFETCH ? PASSES : 1];
     const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DRELU);
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
+    for (int p = 0; p < (PREFETCH ? PASSES : 0); ++p) {
         const int rl = tr + (p % QP) * RPP;
         const int gr = m0 + (p / QP) * 64 + rl;
         const bool ok = col_ok && (rl < 64) && (gr < g.M);
@@ -301,6 +302,20 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : 2) void
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int q = 0; q < WAVES_M; ++q) {
+        // wide tiles: the slab's own epilogue reads are issued here, ahead of its two barriers
+        uint4 rs_v[PREFETCH ? 1 : QP], as_v[PREFETCH ? 1 : QP];
+        if (!PREFETCH) {
+#pragma unroll
+            for (int hp = 0; hp < QP; ++hp) {
+                const int rl = tr + hp * RPP;
+                const int gr = m0 + q * 64 + rl;
+                const bool ok = col_ok && (rl < 64) && (gr < g.M);
+                rs_v[hp] = make_uint4(0, 0, 0, 0);
+                as_v[hp] = make_uint4(0, 0, 0, 0);
+                if (ok && g.residual) rs_v[hp] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
+                if (ok && want_aux) as_v[hp] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
+            }
+        }
         __syncthreads();   // fragment reads (q = 0) / the previous slab's reads are done
         if (wm == q) {
 #pragma unroll
@@ -316,7 +331,8 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : 2) void
                 const int rl = tr + hp * RPP;
                 const int gr = m0 + q * 64 + rl;
                 if (rl < 64 && gr < g.M)
-                    nt_epilogue_row(g, Cs + rl * LDCS + tc, gr, gc, bias, cs, res_v[q * QP + hp], aux_v[q * QP + hp], want_aux);
+                    nt_epilogue_row(g, Cs + rl * LDCS + tc, gr, gc, bias, cs, PREFETCH ? res_v[PREFETCH ? q * QP + hp : 0] : rs_v[PREFETCH ? 0 : hp],
+                                    PREFETCH ? aux_v[PREFETCH ? q * QP + hp : 0] : as_v[PREFETCH ? 0 : hp], want_aux);
             }
         }
     }
@@ -368,7 +384,11 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     static const int use_3wg = getenv("MMG_GEMM_3WG") ? atoi(getenv("MMG_GEMM_3WG")) : 1;
     static const int k3_max = getenv("MMG_GEMM_K3") ? atoi(getenv("MMG_GEMM_K3")) : 384;       // 3-WG config below this K
     static const int kbig_min = getenv("MMG_GEMM_KBIG") ? atoi(getenv("MMG_GEMM_KBIG")) : 512;  // 256x128 config from this K
-    if (use_3wg && !n96 && K % 32 == 0 && K < k3_max) launch_nt<128, 128, 32, 2, 3>(g, stream);
+    // 256x256 tile (8 waves, one workgroup per CU): 128 FLOP per operand byte pulled from L2, which is what bounds the
+    // 128-wide tiles (~10 TB/s of L2->LDS traffic); used from this K upwards when N is a multiple of 256 (0 = never)
+    static const int use_256 = getenv("MMG_GEMM_256") ? atoi(getenv("MMG_GEMM_256")) : 384;
+    if (use_256 && k64 && N % 256 == 0 && M >= 4096 && K >= use_256) launch_nt<256, 256, 64, 4, 2>(g, stream);
+    else if (use_3wg && !n96 && K % 32 == 0 && K < k3_max) launch_nt<128, 128, 32, 2, 3>(g, stream);
     else if (use_big && k64 && !n96 && M >= 4096 && K >= kbig_min) launch_nt<256, 128, 64, 4, 3>(g, stream);
     else if (n96) { if (k64) launch_nt<128, 96, 64, 2, 2>(g, stream); else launch_nt<128, 96, 32, 2, 2>(g, stream); }
     else          { if (k64) launch_nt<128, 128, 64, 2, 2>(g, stream); else launch_nt<128, 128, 32, 2, 2>(g, stream); }

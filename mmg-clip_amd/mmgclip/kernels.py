@@ -103,11 +103,12 @@ def cnblock_supported(C):
 def cnblock_pack(w1, w2, gamma=None, backward=False):
     """Packed bf16 weight image of the fused CNBlock MLP kernels (W1 fp32 [4C,C], W2 fp32 [C,4C])."""
     C = w1.shape[1]
-    n = _hip.load().mmg_cnblock_packed_elems(C, 1 if backward else 0)
+    backward = int(backward)
+    n = _hip.load().mmg_cnblock_packed_elems(C, backward)
     if n <= 0:
         raise ValueError(f"fused CNBlock MLP: C={C} is not supported")
     out = torch.empty(n, device=w1.device, dtype=BF16)
-    call("mmg_cnblock_pack_weights", ptr(w1), ptr(w2), ptr(gamma), ptr(out), C, 1 if backward else 0, stream())
+    call("mmg_cnblock_pack_weights", ptr(w1), ptr(w2), ptr(gamma), ptr(out), C, backward, stream())
     return out
 
 
@@ -123,11 +124,12 @@ def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_h
     return y, hpre, mean, rstd
 
 
-def cnblock_bwd_supported(C):
-    return bool(_hip.load().mmg_cnblock_mlp_bwd_supported(C))
+def cnblock_bwd_mode(C):
+    """0 = no fused backward, 1 = hidden row recomputed, 2 = needs the forward's saved pre-activation."""
+    return int(_hip.load().mmg_cnblock_mlp_bwd_supported(C))
 
 
-def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1):
+def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None):
     """-> dh, g [M,4C]; xln, dxln [M,C]; mean, rstd [M]  (see include/mmgclip_hip.h)."""
     M, C = xd.shape
     dev = xd.device
@@ -136,7 +138,7 @@ def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1):
     xln, dxln = torch.empty_like(xd), torch.empty_like(xd)
     mean = torch.empty(M, device=dev, dtype=torch.float32)
     rstd = torch.empty(M, device=dev, dtype=torch.float32)
-    call("mmg_cnblock_mlp_bwd", ptr(dy), ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed_bwd), ptr(b1), ptr(dh), ptr(g),
+    call("mmg_cnblock_mlp_bwd", ptr(dy), ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed_bwd), ptr(b1), ptr(hpre), ptr(dh), ptr(g),
          ptr(xln), ptr(dxln), ptr(mean), ptr(rstd), M, C, stream())
     return dh, g, xln, dxln, mean, rstd
 

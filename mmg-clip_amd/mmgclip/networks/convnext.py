@@ -133,9 +133,10 @@ class ConvNextTower(nn.Module):
                                                           blk.layer_scale.data.reshape(C))
                 if self.fused_mlp and K.cnblock_supported(C):                                # packed LDS images
                     wc[key + ".mlp"] = K.cnblock_pack(blk.block[3].weight.data, blk.block[5].weight.data)
-                    if K.cnblock_bwd_supported(C):
-                        wc[key + ".mlpb"] = K.cnblock_pack(blk.block[3].weight.data, blk.block[5].weight.data,
-                                                           blk.layer_scale.data.reshape(C), backward=True)
+                    mode = K.cnblock_bwd_mode(C)     # 1: hidden row recomputed; 2: reads the forward's saved pre-activation
+                    if mode:
+                        wc[key + (".mlpb" if mode == 1 else ".mlpb2")] = K.cnblock_pack(
+                            blk.block[3].weight.data, blk.block[5].weight.data, blk.layer_scale.data.reshape(C), backward=mode)
             if si < 3:
                 conv = f[2 + 2 * si][1].weight.data                                          # [2C, C, 2, 2]
                 wds = conv.permute(0, 2, 3, 1).reshape(conv.shape[0], -1).contiguous()       # [(kh,kw,ci)]
@@ -210,9 +211,10 @@ class ConvNextTower(nn.Module):
                 blk = f[1 + 2 * si][bi]
                 key = f"{si}.{bi}"
                 x, d, mean, rstd, hpre = saved[key]
-                if hpre is None:                           # fused data path: hidden row recomputed on chip
+                if hpre is None or key + ".mlpb2" in wc:   # fused data path (hidden row recomputed on chip / read back)
                     dh, g, ln, dln, mean, rstd = K.cnblock_mlp_bwd(dx, d, blk.block[2].weight.data, blk.block[2].bias.data,
-                                                                   LN_EPS, wc[key + ".mlpb"], blk.block[3].bias.data)
+                                                                   LN_EPS, wc[key + (".mlpb" if hpre is None else ".mlpb2")],
+                                                                   blk.block[3].bias.data, hpre)
                     L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
                     del g
                     L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))

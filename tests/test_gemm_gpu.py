@@ -23,7 +23,7 @@ def test_nt_integer_exact_asymmetric(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 96, 96), (384, 384, 96), (512, 768, 3072), (300, 200, 160),
-                                   (64, 512, 768), (1024, 2304, 768), (37, 512, 768), (4096, 192, 768)])
+                                   (64, 512, 768), (1024, 2304, 768), (37, 512, 768), (4096, 192, 768), (4100, 768, 384), (4353, 512, 1536)])
 def test_nt_plain(dev, M, N, K):
     from mmgclip import linalg
     a, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2)
@@ -34,9 +34,9 @@ def test_nt_plain(dev, M, N, K):
     np.testing.assert_allclose(c16.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
 
 
-def test_nt_epilogues(dev):
+@pytest.mark.parametrize("M,N,K", [(512, 384, 96), (4200, 512, 384)])      # second shape: the 256x256 tile path
+def test_nt_epilogues(dev, M, N, K):
     from mmgclip import linalg
-    M, N, K = 512, 384, 96
     a, b = _rand((M, K), dev, 1.0, 3), _rand((N, K), dev, 0.1, 4)
     bias = torch.randn(N, device=dev)
     cs = torch.rand(N, device=dev) + 0.5

@@ -253,7 +253,7 @@ def test_fused_cnblock_mlp_forward_matches_unfused_reference(dev, C, M):
     assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("C,M", [(96, 128 * 3 + 50), (128, 200), (192, 333)])
+@pytest.mark.parametrize("C,M", [(96, 128 * 3 + 50), (128, 200), (192, 333), (384, 128 + 77)])
 def test_fused_cnblock_mlp_backward_data_path(dev, C, M):
     """mmg_cnblock_mlp_bwd vs fp32 torch autograd of the same MLP: g, dh (operands of the weight-gradient GEMMs), LN output,
     gradient w.r.t. the LN output and the LN statistics."""
@@ -273,8 +273,10 @@ def test_fused_cnblock_mlp_backward_data_path(dev, C, M):
     (dh_want,) = torch.autograd.grad(gl, h, dG, retain_graph=True)
     dln_want = dh_want.to(torch.bfloat16).float() @ w1b
     d = lambda t: t.to(dev)   # noqa: E731
-    packed = K.cnblock_pack(d(w1), d(w2), d(gamma), backward=True)
-    dh, gg, xln, dxln, mean, rstd = K.cnblock_mlp_bwd(d(dy), d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1))
+    mode = K.cnblock_bwd_mode(C)
+    packed = K.cnblock_pack(d(w1), d(w2), d(gamma), backward=mode)
+    hsaved = d(h.detach().to(torch.bfloat16)) if mode == 2 else None       # C = 384 reads the forward's pre-activation
+    dh, gg, xln, dxln, mean, rstd = K.cnblock_mlp_bwd(d(dy), d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1), hsaved)
     torch.cuda.synchronize()
     _close(xln, ln.detach(), 1e-2, 1e-2)
     _close(gg, gl.detach(), 2e-2, 2e-2)

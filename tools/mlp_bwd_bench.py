@@ -6,7 +6,8 @@ from mmgclip import kernels as K, linalg as L
 
 dev = torch.device("cuda")
 for C, px, n in ((96, 256 * 256, 64), (192, 128 * 128, 64), (384, 64 * 64, 64)):
-    if not K.cnblock_bwd_supported(C):
+    mode = K.cnblock_bwd_mode(C)
+    if not mode:
         continue
     M = px * n
     g = torch.Generator().manual_seed(0)
@@ -16,12 +17,12 @@ for C, px, n in ((96, 256 * 256, 64), (192, 128 * 128, 64), (384, 64 * 64, 64)):
     w1, b1 = (torch.randn(4 * C, C, generator=g) / C ** 0.5).to(dev), torch.zeros(4 * C, device=dev)
     w2 = (torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5).to(dev)
     gamma = torch.ones(C, device=dev)
-    packed = K.cnblock_pack(w1, w2, gamma, backward=True)
+    packed = K.cnblock_pack(w1, w2, gamma, backward=mode)
     w1t, w2gt = K.transpose_cast_bf16(w1), K.transpose_cast_bf16(w2, gamma)
     hpre = torch.randn(M, 4 * C, device=dev, dtype=torch.bfloat16)
 
     def fused():
-        return K.cnblock_mlp_bwd(dy, xd, lnw, lnb, 1e-6, packed, b1)
+        return K.cnblock_mlp_bwd(dy, xd, lnw, lnb, 1e-6, packed, b1, hpre if mode == 2 else None)
 
     def unfused():
         gg = torch.empty_like(hpre)
