@@ -87,6 +87,7 @@ class ConvNextTower(nn.Module):
         self.variant, self.in_chans, self.scale16, self.micro_batch = variant, in_chans, scale16, micro_batch
         # narrow stages (C <= 256) run the CNBlock MLP as one fused launch; MMG_FUSED_MLP=0 keeps the GEMM pair
         self.fused_mlp = (os.environ.get("MMG_FUSED_MLP", "1") != "0") if fused_mlp is None else bool(fused_mlp)
+        self.fused_bwd_saved_h = os.environ.get("MMG_FUSED_MLP_BWD_SAVED_H", "0") == "1"
         self.dims, self.depths = CONFIGS[variant]["dims"], CONFIGS[variant]["depths"]
         self.model = _TorchvisionLayout(variant, in_chans)
         self.model_output_dimension = self.dims[-1]
@@ -134,6 +135,8 @@ class ConvNextTower(nn.Module):
                 if self.fused_mlp and K.cnblock_supported(C):                                # packed LDS images
                     wc[key + ".mlp"] = K.cnblock_pack(blk.block[3].weight.data, blk.block[5].weight.data)
                     mode = K.cnblock_bwd_mode(C)     # 1: hidden row recomputed; 2: reads the forward's saved pre-activation
+                    if mode == 2 and not self.fused_bwd_saved_h:   # (C=384: slower than the GEMM pair so far)
+                        mode = 0
                     if mode:
                         wc[key + (".mlpb" if mode == 1 else ".mlpb2")] = K.cnblock_pack(
                             blk.block[3].weight.data, blk.block[5].weight.data, blk.layer_scale.data.reshape(C), backward=mode)
