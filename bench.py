@@ -231,16 +231,23 @@ def main():
     }
     if rank == 0:
         if not args.no_roofline:
-            out["roofline"] = linalg.PROFILE.summary(MFMA_BF16_PEAK_TFLOPS)
+            fams = linalg.PROFILE.families()
             # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/collect_traffic.sh; the
             # counters cannot be read from inside the process), corrected as MI355X_MICROARCH.md prescribes
             tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) \
                 if os.path.isdir(os.path.join(ROOT, "profiles")) else []
             default_cmd = (args.batch, args.image_size, args.seq_len, args.micro_batch, args.variant, world) == (256, 1024, 77, 64, "tiny", 1)
-            if tfile and default_cmd and out["roofline"]:
-                t = json.load(open(os.path.join(ROOT, "profiles", tfile[-1])))
-                out["roofline"]["traffic"] = round(t["gemm_nt_kernel"]["hbm_bytes_per_launch"])
-                out["roofline"]["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile[-1]
+            traffic = json.load(open(os.path.join(ROOT, "profiles", tfile[-1]))).get("families", {}) if (tfile and default_cmd) else {}
+            lines = []
+            for fam, st in fams.items():
+                r = linalg.PROFILE.roofline(fam, st)
+                if fam in traffic:
+                    r["traffic"] = round(traffic[fam]["hbm_bytes_per_launch"])
+                    r["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile[-1]
+                lines.append(r)
+            if lines:
+                out["roofline"] = lines[0]                 # the kernel with the largest share of the timed region
+                out["roofline_other_kernels"] = lines[1:]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -18,6 +18,7 @@
 //     16x16x32 step (the k-order this implies is folded into the packing of W2) - no LDS round trip for the hidden row.
 // The bound is the fp32 VALU (erf-GELU, ~18 ops per hidden element = 3x the MFMA time at C=96), then HBM.
 #include "common.h"
+#include <stdlib.h>
 
 
 struct MlpFwd {

@@ -44,9 +44,13 @@ def init_from_env(backend=None):
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-        dist.init_process_group(backend=backend)
+            idx = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+            torch.cuda.set_device(idx)
+            if backend == "nccl":           # bind the communicator to this rank's GPU up front (no lazy device guess)
+                kw["device_id"] = torch.device("cuda", idx)
+        dist.init_process_group(backend=backend, **kw)
     return Comm()
 
 

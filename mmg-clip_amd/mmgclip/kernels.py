@@ -6,6 +6,7 @@ import torch
 
 from . import _hip
 from ._hip import call, ptr, stream
+from .profile import PROFILE
 
 BF16 = torch.bfloat16
 
@@ -88,12 +89,16 @@ def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0)
 
 def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None):
     y = out if out is not None else torch.empty(n * H * W, C, device=x.device, dtype=BF16)
-    call("mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream())
+    px = n * H * W * C
+    PROFILE.timed("dwconv7_kernel", 98.0 * px, (6 if add is not None else 4) * px,
+                  lambda: call("mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()))
     return y
 
 
 def dwconv7_wgrad(x, dy, dw49, dbias, n, H, W, C):
-    call("mmg_dwconv7_wgrad", ptr(x), ptr(dy), ptr(dw49), ptr(dbias), n, H, W, C, stream())
+    px = n * H * W * C
+    PROFILE.timed("dwconv7_wgrad_kernel", 98.0 * px, 4 * px,
+                  lambda: call("mmg_dwconv7_wgrad", ptr(x), ptr(dy), ptr(dw49), ptr(dbias), n, H, W, C, stream()))
 
 
 def cnblock_supported(C):
@@ -119,8 +124,9 @@ def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_h
     assert want_hpre == want_stats, "hpre and the LN statistics are saved together"
     mean = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
-    call("mmg_cnblock_mlp_fwd", ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed), ptr(b1), ptr(b2), ptr(gamma),
-         ptr(residual), ptr(y), ptr(hpre), ptr(mean), ptr(rstd), M, C, stream())
+    PROFILE.timed("cnblock_mlp_fwd_kernel", 16.0 * M * C * C, (6 + (8 if want_hpre else 0)) * M * C + 16 * C * C,
+                  lambda: call("mmg_cnblock_mlp_fwd", ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed), ptr(b1), ptr(b2),
+                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(mean), ptr(rstd), M, C, stream()))
     return y, hpre, mean, rstd
 
 
@@ -138,8 +144,10 @@ def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None):
     xln, dxln = torch.empty_like(xd), torch.empty_like(xd)
     mean = torch.empty(M, device=dev, dtype=torch.float32)
     rstd = torch.empty(M, device=dev, dtype=torch.float32)
-    call("mmg_cnblock_mlp_bwd", ptr(dy), ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed_bwd), ptr(b1), ptr(hpre), ptr(dh), ptr(g),
-         ptr(xln), ptr(dxln), ptr(mean), ptr(rstd), M, C, stream())
+    # algorithmic work: dG and dX GEMMs (the recomputed hidden GEMM is overhead, not counted); reads dy, xd (+h), writes dh, g, xln, dxln
+    PROFILE.timed("cnblock_mlp_bwd_kernel", 16.0 * M * C * C, (24 + (8 if hpre is not None else 0)) * M * C + 24 * C * C,
+                  lambda: call("mmg_cnblock_mlp_bwd", ptr(dy), ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed_bwd), ptr(b1),
+                               ptr(hpre), ptr(dh), ptr(g), ptr(xln), ptr(dxln), ptr(mean), ptr(rstd), M, C, stream()))
     return dh, g, xln, dxln, mean, rstd
 
 

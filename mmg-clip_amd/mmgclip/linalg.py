@@ -45,48 +45,29 @@ def colsum_acc(a, out):
     return out
 
 
-class _GemmProfile:
-    """HIP-event timing of every gemm_nt launch (bench.py's roofline leg).  Events are recorded on the stream the kernel
-    is launched on (torch's current stream), so the durations are the kernel's own; flops are the algorithmic 2*M*N*K."""
+from .profile import PROFILE  # noqa: E402  (bench.py reads linalg.PROFILE)
 
-    def __init__(self):
-        self.on = False
-        self.records = []        # (start, end, flops, bytes)
-
-    def enable(self):
-        self.on, self.records = True, []
-
-    def disable(self):
-        self.on = False
-
-    def summary(self, peak_tflops):
-        if not self.records:
-            return None
-        torch.cuda.synchronize()
-        t_ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
-        flops = sum(f for _, _, f, _ in self.records)
-        byts = sum(b for _, _, _, b in self.records)
-        n = len(self.records)
-        ach = flops / (t_ms * 1e-3) / 1e12
-        return {"kernel": "gemm_nt_kernel (bf16 MFMA, all shapes of the step)", "bound": "mfma", "achieved": round(ach, 1),
-                "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4), "traffic": None,
-                "launches": n, "avg_launch_us": round(t_ms * 1000.0 / n, 1), "total_ms": round(t_ms, 2),
-                "algorithmic_bytes_per_launch": round(byts / n), "algorithmic_gbytes_per_s": round(byts / (t_ms * 1e-3) / 1e9, 1)}
-
-
-PROFILE = _GemmProfile()
 _gemm_nt_raw = gemm_nt
+_gemm_tn_raw = gemm_tn_acc
 
 
 def gemm_nt(a, b, out=None, **kw):       # noqa: F811  (profiling shim around the launch)
     if not PROFILE.on:
         return _gemm_nt_raw(a, b, out=out, **kw)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    r = _gemm_nt_raw(a, b, out=out, **kw)
-    e.record()
     M, K = a.shape
     N = b.shape[0]
-    byts = 2 * (M * K + N * K) + r.element_size() * M * N
-    PROFILE.records.append((s, e, 2.0 * M * N * K, byts))
-    return r
+    esz = 4 if (out is not None and out.dtype == torch.float32) or kw.get("out_dtype") == torch.float32 else 2
+    nbytes = 2 * (M * K + N * K) + esz * M * N
+    for extra in ("residual", "aux_in", "aux_out"):
+        if kw.get(extra) is not None:
+            nbytes += 2 * M * N
+    return PROFILE.timed("gemm_nt_kernel", 2.0 * M * N * K, nbytes, lambda: _gemm_nt_raw(a, b, out=out, **kw))
+
+
+def gemm_tn_acc(a, b, out, alpha=1.0, colsum=None):       # noqa: F811
+    if not PROFILE.on:
+        return _gemm_tn_raw(a, b, out, alpha, colsum)
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    return PROFILE.timed("gemm_tn_kernel", 2.0 * M * N1 * N2, 2 * M * (N1 + N2) + 4 * N1 * N2,
+                         lambda: _gemm_tn_raw(a, b, out, alpha, colsum))

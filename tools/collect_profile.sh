@@ -23,11 +23,15 @@ md = [f"# {tag} — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-c
       "| kernel | calls | total ms | avg us | % of GPU time |", "|---|---|---|---|---|"]
 for r in rows[:24]:
     md.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.1f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
-nt = [r for r in rows if "gemm_nt_kernel" in r["Name"]]
-n = sum(int(r["Calls"]) for r in nt); t = sum(float(r["TotalDurationNs"]) for r in nt)
-md += ["", f"Sum of kernel time {tot/1e6:.0f} ms over {steps} steps = {tot/1e6/steps:.0f} ms/step vs {b['ms_per_step']:.0f} ms/step wall under the profiler.",
-       f"`gemm_nt_kernel` (all instantiations): {n} launches, {t/1e6:.1f} ms, average {t/1e3/n:.1f} us per launch "
-       f"(bench.py's HIP-event figure in the same run: {b['roofline'].get('launches')} launches, {b['roofline'].get('avg_launch_us')} us average)."]
+md += ["", f"Sum of kernel time {tot/1e6:.0f} ms over {steps} steps = {tot/1e6/steps:.0f} ms/step vs {b['ms_per_step']:.0f} ms/step wall under the profiler.", ""]
+for rl in [b["roofline"]] + b.get("roofline_other_kernels", []):
+    fam = rl["kernel"]
+    sel = [r for r in rows if r["Name"].replace("void ", "").split("<")[0].split("(")[0].strip() == fam]
+    if not sel:
+        continue
+    n = sum(int(r["Calls"]) for r in sel); t = sum(float(r["TotalDurationNs"]) for r in sel)
+    md.append(f"`{fam}` (all instantiations, all {steps} steps): {n} launches, {t/1e6:.1f} ms, average {t/1e3/n:.1f} us per launch "
+              f"(bench.py's HIP-event figure for the {b['steps']} timed steps of the same run: {rl['launches']} launches, {rl['avg_launch_us']} us average).")
 open(f"{out}/{tag}_bench_default.md", "w").write("\n".join(md) + "\n")
 print(md[-1])
 PY

@@ -29,12 +29,15 @@ kernels = {}
 for k, (n, kb) in res["FETCH_SIZE"].items():
     w = res["WRITE_SIZE"].get(k, [0, 0.0])
     kernels[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * kb * 1024 / n, "write_bytes_per_launch": w[1] * 1024 / max(w[0], 1)}
-nt = {k: v for k, v in kernels.items() if "gemm_nt_kernel" in k}
-n = sum(v["launches"] for v in nt.values())
-tot = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in nt.values())
+fam = collections.defaultdict(lambda: [0, 0.0])        # kernel family = symbol name without template arguments
+for k, v in kernels.items():
+    f = k.replace("void ", "").split("<")[0].strip()
+    fam[f][0] += v["launches"]
+    fam[f][1] += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+families = {f: {"launches": n, "hbm_bytes_per_launch": tot / n} for f, (n, tot) in fam.items() if n}
 summary = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-roofline",
            "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE x1, KiB -> bytes",
-           "gemm_nt_kernel": {"launches": n, "hbm_bytes_per_launch": tot / n}, "kernels": kernels}
+           "families": families, "kernels": kernels}
 json.dump(summary, open(out + "/traffic.json", "w"), indent=1)
-print(json.dumps(summary["gemm_nt_kernel"]))
+print(json.dumps({f: families[f] for f in ("gemm_nt_kernel", "gemm_tn_kernel", "cnblock_mlp_fwd_kernel", "cnblock_mlp_bwd_kernel") if f in families}))
 PY
