@@ -193,11 +193,14 @@ int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, fl
  * be NULL and the forward saves nothing 4C-wide; 2 (C = 384) = h is read back from the forward's hpre, packed_bwd =
  * pack(..., backward=2); 0 = unsupported.  Writes g = GELU(h), dh = (dy gamma W2) * GELU'(h) (bf16 [M,4C], operands of the
  * weight-gradient GEMMs dW2 = dy^T g, dW1 = dh^T xln), xln = LN(xd) and dxln = dh W1 (bf16 [M,C]) and the LN statistics for
- * mmg_layernorm_bwd.  (New capability: the reference never trains the image tower, mmgclip/networks/encoder.py:53.) */
+ * mmg_layernorm_bwd.  With ln_dw / ln_db (fp32 [C], accumulated) the LayerNorm backward is fused into the epilogue: dxln then
+ * receives d loss / d xd and no mmg_layernorm_bwd launch is needed.
+ * (New capability: the reference never trains the image tower, mmgclip/networks/encoder.py:53.) */
 int mmg_cnblock_mlp_bwd_supported(int C);
 int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps,
                         const void* packed_bwd, const float* b1, const void* hpre, void* dh, void* g, void* xln,
-                        void* dxln, float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
+                        void* dxln, float* mean, float* rstd, float* ln_dw, float* ln_db, long long M, int C,
+                        mmg_stream_t stream);
 
 /* ---- BERT attention / embeddings / pooling -------------------------------------------------------------------- */
 

@@ -264,13 +264,23 @@ struct MlpBwd {
     bf16_t* xln; bf16_t* dxln;              // [M,C] LN output (operand of dW1), gradient w.r.t. the LN output
     float* mean; float* rstd;               // [M] for the LayerNorm backward
     const bf16_t* hpre;                     // [M,4C] saved pre-activation (RECOMP = false only)
+    float* ln_dw; float* ln_db;             // optional [C]: fuse the LayerNorm backward (dxln then receives d loss / d xd)
     long M; int ntiles;
 };
+
+// sum over the 16 lanes of a DPP row (the lanes that share the same output columns); every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
 
 // RECOMP = false (C = 384): the pre-activation is read back from the forward's `hpre` instead of being recomputed, so the
 // W1 part, its MFMAs and the LN-output fragments drop out (one 16-row tile per wave cannot afford them: registers, and one
 // LDS fragment read per MFMA); chunks are then [gamma*W2^T | W1^T].
-template <int C, bool RECOMP>
+template <int C, bool RECOMP, bool LNB>
 __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnblock_mlp_bwd_kernel(const MlpBwd p) {
     constexpr int NC = MlpCfg<C>::NC, MT = MlpCfg<C>::MT, MLP_THREADS = MlpCfg<C>::THREADS, MLP_BM = MlpCfg<C>::BM;
     constexpr int KS1 = C / 32, CT = C / 16, NSUB = NC / 32, NCH = 4 * C / NC;
@@ -280,9 +290,11 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
     static_assert(NCH % 2 == 0, "ring parity is carried across tiles");
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_lnw = reinterpret_cast<float*>(smem + 2 * CHUNK);   // [C] [C] [4C]
+    float* s_lnw = reinterpret_cast<float*>(smem + 2 * CHUNK);   // [C] [C] [4C] [C] [C]
     float* s_lnb = s_lnw + C;
     float* s_b1 = s_lnb + C;
+    float* s_dg = s_b1 + 4 * C;                                  // LayerNorm weight / bias gradient of this workgroup
+    float* s_db = s_dg + C;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
@@ -294,13 +306,14 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
         for (int it = 0; it < LOADS; ++it) mlp_glds16(s + it * (MLP_THREADS * 16), lds_wave + buf * CHUNK + it * (MLP_THREADS * 16));
     };
     if ((int)blockIdx.x < p.ntiles) stage(0, 0);
-    for (int i = tid; i < C; i += MLP_THREADS) { s_lnw[i] = p.ln_w[i]; s_lnb[i] = p.ln_b[i]; }
+    for (int i = tid; i < C; i += MLP_THREADS) { s_lnw[i] = p.ln_w[i]; s_lnb[i] = p.ln_b[i]; s_dg[i] = 0.f; s_db[i] = 0.f; }
     for (int i = tid; i < 4 * C; i += MLP_THREADS) s_b1[i] = p.b1[i];
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const long row0 = (long)tile * MLP_BM + wave * (16 * MT) + li;
         bf16x8 xf[RECOMP ? MT : 1][RECOMP ? KS1 : 1], dyf[MT][KS1];
+        float row_mean[MT], row_rstd[MT];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
@@ -333,6 +346,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
             q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
             const float rstd = rsqrtf(q * (1.0f / C) + p.eps);
             if (lg == 0 && row < p.M) { p.mean[row] = mean; p.rstd[row] = rstd; }
+            row_mean[mi] = mean; row_rstd[mi] = rstd;
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_lnw + 32 * ks + 8 * lg);
@@ -436,17 +450,75 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                 }
             }
         }
+        if (!LNB) {
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const long row = row0 + 16 * mi;
-            if (row < p.M) {
+            for (int mi = 0; mi < MT; ++mi) {
+                const long row = row0 + 16 * mi;
+                if (row < p.M) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const f32x4 a = dxacc[mi][ct];
+                        *reinterpret_cast<uint2*>(p.dxln + row * C + ct * 16 + 4 * lg) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+                    }
+                }
+            }
+        } else {
+            // LayerNorm backward on the accumulators (lane = row, 4 consecutive columns per 16-column tile):
+            //   g = dxln * gamma,  d xd = rstd * (g - mean(g) - xhat * mean(g * xhat)),  dgamma += dxln * xhat,  dbeta += dxln
+            uint2 xv[MT][CT];
+            float m1[MT], m2[MT];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                const long row = row0 + 16 * mi;
+                const long rr = row < p.M ? row : p.M - 1;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) xv[mi][ct] = *reinterpret_cast<const uint2*>(p.xd + rr * C + ct * 16 + 4 * lg);
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const f32x4 a = dxacc[mi][ct];
-                    *reinterpret_cast<uint2*>(p.dxln + row * C + ct * 16 + 4 * lg) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + ct * 16 + 4 * lg);
+                    const float x[4] = {bf2f_lo(xv[mi][ct].x), bf2f_hi(xv[mi][ct].x), bf2f_lo(xv[mi][ct].y), bf2f_hi(xv[mi][ct].y)};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (x[r] - row_mean[mi]) * row_rstd[mi];
+                        const float gg = dxacc[mi][ct][r] * gm[r];
+                        s1 += gg; s2 = fmaf(gg, xh, s2);
+                    }
+                }
+                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+                m1[mi] = s1 * (1.0f / C); m2[mi] = s2 * (1.0f / C);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + ct * 16 + 4 * lg);
+                float cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const long row = row0 + 16 * mi;
+                    const bool ok = row < p.M;
+                    const float x[4] = {bf2f_lo(xv[mi][ct].x), bf2f_hi(xv[mi][ct].x), bf2f_lo(xv[mi][ct].y), bf2f_hi(xv[mi][ct].y)};
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (x[r] - row_mean[mi]) * row_rstd[mi];
+                        const float dv = ok ? dxacc[mi][ct][r] : 0.f;
+                        o[r] = row_rstd[mi] * (fmaf(-xh, m2[mi], dv * gm[r]) - m1[mi]);
+                        cg[r] = fmaf(dv, xh, cg[r]); cb[r] += dv;
+                    }
+                    if (ok) *reinterpret_cast<uint2*>(p.dxln + row * C + ct * 16 + 4 * lg) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float tg = row16_sum(cg[r]), tb = row16_sum(cb[r]);
+                    if (li == 0) { atomicAdd(s_dg + ct * 16 + 4 * lg + r, tg); atomicAdd(s_db + ct * 16 + 4 * lg + r, tb); }
                 }
             }
         }
+    }
+    if (LNB) {
+        __syncthreads();
+        for (int i = tid; i < C; i += MLP_THREADS) { atomicAdd(p.ln_dw + i, s_dg[i]); atomicAdd(p.ln_db + i, s_db[i]); }
     }
 }
 
@@ -463,12 +535,17 @@ static int mlp_cu_count() {
 template <int C, bool RECOMP>
 static int launch_mlp_bwd(MlpBwd p, hipStream_t stream) {
     typedef MlpCfg<C> Cfg;
-    const size_t lds = 2 * ((RECOMP ? 3 : 2) * Cfg::NC * C * 2) + (size_t)6 * C * sizeof(float);
+    const size_t lds = 2 * ((RECOMP ? 3 : 2) * Cfg::NC * C * 2) + (size_t)8 * C * sizeof(float);
     p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     const int cap = Cfg::WGS_BWD * mlp_cu_count();
     const int grid = p.ntiles < cap ? p.ntiles : cap;
-    mmg_allow_lds(cnblock_mlp_bwd_kernel<C, RECOMP>, lds);
-    hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C, RECOMP>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
+    if (p.ln_dw) {
+        mmg_allow_lds(cnblock_mlp_bwd_kernel<C, RECOMP, true>, lds);
+        hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C, RECOMP, true>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
+    } else {
+        mmg_allow_lds(cnblock_mlp_bwd_kernel<C, RECOMP, false>, lds);
+        hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C, RECOMP, false>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
+    }
     MMG_LAUNCH_CHECK("mmg_cnblock_mlp_bwd");
     return 0;
 }
@@ -548,15 +625,17 @@ MMG_API int mmg_cnblock_mlp_bwd_supported(int C) { return (C == 96 || C == 128 |
 
 MMG_API int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps,
                                 const void* packed_bwd, const float* b1, const void* hpre, void* dh, void* g, void* xln,
-                                void* dxln, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
+                                void* dxln, float* mean, float* rstd, float* ln_dw, float* ln_db, long long M, int C,
+                                hipStream_t stream) {
     MMG_CHECK_ARG(dy && xd && ln_w && ln_b && packed_bwd && b1 && dh && g && xln && dxln && mean && rstd,
                   "mmg_cnblock_mlp_bwd: null pointer");
     const int mode = mmg_cnblock_mlp_bwd_supported(C);
     MMG_CHECK_ARG(mode != 0, "mmg_cnblock_mlp_bwd: C=%d not in {96,128,192,384}", C);
     MMG_CHECK_ARG((mode == 2) == (hpre != nullptr), "mmg_cnblock_mlp_bwd: hpre is required for C=384 and unused otherwise (C=%d)", C);
     MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_bwd: bad M=%lld", M);
+    MMG_CHECK_ARG((ln_dw == nullptr) == (ln_db == nullptr), "mmg_cnblock_mlp_bwd: ln_dw and ln_db go together");
     MlpBwd p{(const bf16_t*)dy, (const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed_bwd, b1, (bf16_t*)dh, (bf16_t*)g,
-             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (const bf16_t*)hpre, (long)M, 0};
+             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (const bf16_t*)hpre, ln_dw, ln_db, (long)M, 0};
     switch (C) {
         case 96: return launch_mlp_bwd<96, true>(p, stream);
         case 128: return launch_mlp_bwd<128, true>(p, stream);

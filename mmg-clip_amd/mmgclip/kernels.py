@@ -135,8 +135,9 @@ def cnblock_bwd_mode(C):
     return int(_hip.load().mmg_cnblock_mlp_bwd_supported(C))
 
 
-def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None):
-    """-> dh, g [M,4C]; xln, dxln [M,C]; mean, rstd [M]  (see include/mmgclip_hip.h)."""
+def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None, ln_grads=None):
+    """-> dh, g [M,4C]; xln, dxln [M,C]; mean, rstd [M]  (see include/mmgclip_hip.h).  With ln_grads = (dgamma, dbeta) the
+    LayerNorm backward is fused: dxln is then the gradient w.r.t. xd and the two fp32 [C] buffers are accumulated."""
     M, C = xd.shape
     dev = xd.device
     dh = torch.empty(M, 4 * C, device=dev, dtype=BF16)
@@ -147,7 +148,8 @@ def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None):
     # algorithmic work: dG and dX GEMMs (the recomputed hidden GEMM is overhead, not counted); reads dy, xd (+h), writes dh, g, xln, dxln
     PROFILE.timed("cnblock_mlp_bwd_kernel", 16.0 * M * C * C, (24 + (8 if hpre is not None else 0)) * M * C + 24 * C * C,
                   lambda: call("mmg_cnblock_mlp_bwd", ptr(dy), ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed_bwd), ptr(b1),
-                               ptr(hpre), ptr(dh), ptr(g), ptr(xln), ptr(dxln), ptr(mean), ptr(rstd), M, C, stream()))
+                               ptr(hpre), ptr(dh), ptr(g), ptr(xln), ptr(dxln), ptr(mean), ptr(rstd),
+                               ptr(ln_grads[0]) if ln_grads else None, ptr(ln_grads[1]) if ln_grads else None, M, C, stream()))
     return dh, g, xln, dxln, mean, rstd
 
 

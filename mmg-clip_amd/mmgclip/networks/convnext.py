@@ -215,9 +215,15 @@ class ConvNextTower(nn.Module):
                 key = f"{si}.{bi}"
                 x, d, mean, rstd, hpre = saved[key]
                 if hpre is None or key + ".mlpb2" in wc:   # fused data path (hidden row recomputed on chip / read back)
-                    dh, g, ln, dln, mean, rstd = K.cnblock_mlp_bwd(dx, d, blk.block[2].weight.data, blk.block[2].bias.data,
-                                                                   LN_EPS, wc[key + (".mlpb" if hpre is None else ".mlpb2")],
-                                                                   blk.block[3].bias.data, hpre)
+                    # C <= 128: the LayerNorm backward rides in the epilogue (`dd` comes back instead of d LN-out); wider
+                    # blocks have no registers left for it
+                    fuse_ln = C <= 128
+                    dh, g, ln, dln, mean, rstd = K.cnblock_mlp_bwd(
+                        dx, d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS,
+                        wc[key + (".mlpb" if hpre is None else ".mlpb2")], blk.block[3].bias.data, hpre,
+                        ln_grads=(gname(blk.block[2], "weight"), gname(blk.block[2], "bias")) if fuse_ln else None)
+                    if fuse_ln:
+                        dd, dln = dln, None
                     L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
                     del g
                     L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
@@ -232,8 +238,9 @@ class ConvNextTower(nn.Module):
                     del ln
                     dln = L.gemm_nt(dh, wc[key + ".w1t"])
                     del dh
-                dd = K.layernorm_bwd(dln, d, mean, rstd, blk.block[2].weight.data, gname(blk.block[2], "weight"),
-                                     gname(blk.block[2], "bias"))
+                if dln is not None:
+                    dd = K.layernorm_bwd(dln, d, mean, rstd, blk.block[2].weight.data, gname(blk.block[2], "weight"),
+                                         gname(blk.block[2], "bias"))
                 del dln
                 K.dwconv7_wgrad(x, dd, tmp[key + ".dw49"], gname(blk.block[0], "bias"), n, h, w_, C)
                 dx = K.dwconv7(dd, wc[key + ".w49"], None, n, h, w_, C, add=dx, flip=True)

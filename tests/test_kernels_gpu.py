@@ -284,3 +284,30 @@ def test_fused_cnblock_mlp_backward_data_path(dev, C, M):
     _close(dxln, dln_want, 2e-2, 3e-2)
     _close(mean, xd.float().mean(1), 1e-5, 1e-5)
     _close(rstd, (xd.float().var(1, unbiased=False) + 1e-6).rsqrt(), 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("C,M", [(96, 128 * 2 + 61), (128, 170)])
+def test_fused_cnblock_mlp_backward_with_layernorm_backward(dev, C, M):
+    """ln_dw / ln_db given: the epilogue also applies the LayerNorm backward (d loss / d xd, dgamma, dbeta) — compared with
+    fp32 torch autograd of LN -> Linear -> GELU from the same d(GELU output)."""
+    from mmgclip import kernels as K
+    g_ = torch.Generator().manual_seed(11 * C + M)
+    xd = torch.randn(M, C, generator=g_).to(torch.bfloat16)
+    dy = (0.5 * torch.randn(M, C, generator=g_)).to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * torch.randn(C, generator=g_), 0.1 * torch.randn(C, generator=g_)
+    w1, b1 = torch.randn(4 * C, C, generator=g_) / C ** 0.5, 0.1 * torch.randn(4 * C, generator=g_)
+    w2 = torch.randn(C, 4 * C, generator=g_) / (4 * C) ** 0.5
+    gamma = 0.3 + 0.7 * torch.rand(C, generator=g_)
+    w1b, w2g = w1.to(torch.bfloat16).float(), (w2 * gamma[:, None]).to(torch.bfloat16).float()
+    x = xd.float().requires_grad_(True)
+    pw, pb = lnw.clone().requires_grad_(True), lnb.clone().requires_grad_(True)
+    gl = F.gelu(F.layer_norm(x, (C,), pw, pb, 1e-6) @ w1b.t() + b1)
+    dx_want, dw_want, db_want = torch.autograd.grad(gl, (x, pw, pb), dy.float() @ w2g)
+    d = lambda t: t.to(dev)   # noqa: E731
+    packed = K.cnblock_pack(d(w1), d(w2), d(gamma), backward=1)
+    dw, db = torch.full((C,), 0.5, device=dev), torch.full((C,), -0.25, device=dev)        # accumulated into
+    _, _, _, dd, _, _ = K.cnblock_mlp_bwd(d(dy), d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1), None, ln_grads=(dw, db))
+    torch.cuda.synchronize()
+    _close(dd, dx_want, 3e-2, 3e-2)
+    rel = lambda a, b: float((a.cpu() - b).norm() / b.norm())   # noqa: E731
+    assert rel(dw - 0.5, dw_want) < 2e-2 and rel(db + 0.25, db_want) < 2e-2, (rel(dw - 0.5, dw_want), rel(db + 0.25, db_want))
