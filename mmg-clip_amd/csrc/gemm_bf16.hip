@@ -406,6 +406,7 @@ struct GemmTN {
     float* colsum_a;          // [N1] += column sums of A (bias gradient of the same linear), nullable
     int tiles1, tiles2, rows_per_chunk;
     float alpha;
+    int chunks, xcd_order;    // xcd_order: 0 = (tile, chunk) grid, 1 / 2 = XCD-grouped by the B / A block (see the kernel)
 };
 
 #define TN_T 128     // output tile edge
@@ -454,8 +455,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const GemmTN g
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int w1 = wave >> 1, w2 = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
-    const int tile = blockIdx.x, chunk = blockIdx.y;
-    const int t1 = tile / g.tiles2, t2 = tile - t1 * g.tiles2;
+    // Workgroup -> (tile, reduction chunk).  The hardware deals workgroups to the 8 XCDs round-robin (XCD = id % 8) and every
+    // output tile (t1, t2) streams operand block t1 of A and t2 of B for its chunk of rows.  The tiles that share a block of
+    // the WIDER operand for one chunk form a group; a group runs back to back on ONE XCD (its L2 then fetches that block once
+    // instead of once per XCD) and consecutive groups go to consecutive XCDs.  (Putting a whole chunk on one XCD was
+    // measured 1.5-3x slower: every workgroup of the XCD then hits the same L2 channels at the same time.)
+    int t1, t2, chunk;
+    if (g.xcd_order) {
+        const int L = blockIdx.x, xcd = L & 7, i = L >> 3;
+        const int G = g.xcd_order == 1 ? g.tiles1 : g.tiles2;            // group size = tiles of the narrow operand
+        const int nwide = g.xcd_order == 1 ? g.tiles2 : g.tiles1;
+        const int slot = i / G, m = i - slot * G, grp = slot * 8 + xcd;
+        if (grp >= nwide * g.chunks) return;
+        chunk = grp / nwide;
+        const int wide = grp - chunk * nwide;
+        if (g.xcd_order == 1) { t1 = m; t2 = wide; } else { t1 = wide; t2 = m; }
+    } else {
+        const int tile = blockIdx.x;
+        chunk = blockIdx.y;
+        t1 = tile / g.tiles2; t2 = tile - t1 * g.tiles2;
+    }
     const int c1 = t1 * TN_T, c2 = t2 * TN_T;
     const int m_begin = chunk * g.rows_per_chunk;
     const int m_end = min(m_begin + g.rows_per_chunk, g.M);
@@ -556,17 +575,28 @@ MMG_API int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, flo
     g.tiles2 = cdiv(N2, TN_T);
     const int tiles = g.tiles1 * g.tiles2;
     static const int target_wgs = getenv("MMG_TN_WGS") ? atoi(getenv("MMG_TN_WGS")) : 512;
+    static const int xcd = getenv("MMG_TN_XCD") ? atoi(getenv("MMG_TN_XCD")) : 1;
     int chunks = target_wgs / tiles;
     if (chunks < 1) chunks = 1;
     const int max_chunks = cdiv(M, TN_BK);
     if (chunks > max_chunks) chunks = max_chunks;
     g.rows_per_chunk = cdiv(cdiv(M, chunks), TN_BK) * TN_BK;
     chunks = cdiv(M, g.rows_per_chunk);
+    g.chunks = chunks;
+    g.xcd_order = xcd ? (N2 >= N1 ? 1 : 2) : 0;
+    if (g.xcd_order) {       // whole groups per XCD: fall back when that would overfill an XCD's share of the workgroup budget
+        const int G = g.xcd_order == 1 ? g.tiles1 : g.tiles2, ngroups = (tiles / G) * chunks;
+        if (((ngroups + 7) / 8) * G * 8 > target_wgs && tiles * chunks <= target_wgs) g.xcd_order = 0;
+    }
     const size_t stage = 4 * (size_t)(TN_BK * TN_T * 2);
     const size_t cs = (size_t)TN_T * (TN_T + 4) * 4;
     const size_t shm = stage > cs ? stage : cs;
     mmg_allow_lds(gemm_tn_kernel, shm);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks), dim3(GEMM_THREADS), shm, stream, g);
+    if (g.xcd_order) {
+        const int G = g.xcd_order == 1 ? g.tiles1 : g.tiles2, ngroups = (tiles / G) * chunks;
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(8 * ((ngroups + 7) / 8) * G), dim3(GEMM_THREADS), shm, stream, g);
+    }
+    else hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks), dim3(GEMM_THREADS), shm, stream, g);
     MMG_LAUNCH_CHECK("mmg_gemm_tn_bf16");
     return 0;
 }
