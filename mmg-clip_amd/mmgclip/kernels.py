@@ -87,11 +87,11 @@ def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0)
          float(eps), float(wd), int(step), float(grad_scale), stream())
 
 
-def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None):
+def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None, mfma=False):
     y = out if out is not None else torch.empty(n * H * W, C, device=x.device, dtype=BF16)
     px = n * H * W * C
     PROFILE.timed("dwconv7_kernel", 98.0 * px, (6 if add is not None else 4) * px,
-                  lambda: call("mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()))
+                  lambda: call("mmg_dwconv7_nhwc_mfma" if mfma else "mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()))
     return y
 
 

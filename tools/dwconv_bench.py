@@ -15,6 +15,7 @@ def timeit(fn, iters=5):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
 
+print("env", {k: v for k, v in os.environ.items() if k.startswith("MMG_")})
 for n, H, C in [(16, 256, 96), (16, 128, 192), (16, 64, 384), (16, 32, 768)]:
     x = torch.randn(n * H * H, C, device=dev).bfloat16()
     dy = torch.randn(n * H * H, C, device=dev).bfloat16()
