@@ -55,8 +55,12 @@ template <int C> struct MlpCfg {
 // chunk j (hidden columns j*NC .. +NC) is a sequence of parts, each an LDS image of NC*C bf16:
 //   A-type part : (C/8) k-granules x NC rows x 8   element (n, c), K = c           (weight fragment of  . x [*, C]^T)
 //   B-type part : (NC/8) k-granules x C rows x 8   element (c, n), K = n PERMUTED  (weight fragment of  hidden x [C, *]^T)
-// K permutation of a B-type part inside each group of 32 hidden columns: slot 8q+j holds column (j<4 ? 4q+j : 16+4q+j-4),
-// the order in which two swapped-MFMA accumulator tiles present the hidden row as a B operand.
+// Hidden-unit order: after the swapped MFMA a lane (row li, group q = lane >> 4) holds 4 consecutive ROW POSITIONS 4q..4q+3 of
+// each of the two 16-row weight tiles of a 32-unit group.  The A-type image places hidden unit 8q + 4tt + r at position
+// (tile tt, 4q + r), so the lane's two tiles are the 8 CONSECUTIVE units 8q..8q+7: one 16-byte store / load per lane for the
+// 4C-wide tensors (8-byte pieces were bound by the texture-address path), and the k slot 8q + j that the pair of tiles
+// presents as a B operand is hidden unit 8q + j, i.e. the K order of B-type parts is natural.  The ROWS of a B-type part
+// (output columns c of the C-wide results) follow the same rule, so those leave as 16-byte pieces too.
 // A source is W1-like ([4C, C], element (n, c) at n*C + c) or W2-like ([C, 4C], element (n, c) at c*4C + n); `scale` ([C],
 // optional) multiplies by scale[c] (folds the layer scale into W2^T for the backward).
 struct PackPart { const float* src; int w2_like; const float* scale; int btype; };
@@ -74,12 +78,14 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const PackArgs a) {
         int n, c;
         if (!pp.btype) {
             const int kg = (int)(off / (NC * 8)), nn = (int)((off / 8) % NC), jj = (int)(off % 8);
-            n = j * NC + nn; c = 8 * kg + jj;
+            // row position nn of the image = 32-column group, MFMA tile tt, lane group q, register r  ->  hidden unit 8q + 4tt + r
+            const int g32 = nn >> 5, tt = (nn >> 4) & 1, q = (nn >> 2) & 3, r = nn & 3;
+            n = j * NC + 32 * g32 + 8 * q + 4 * tt + r; c = 8 * kg + jj;
         } else {
             const int kg = (int)(off / (C * 8)), jj = (int)(off % 8);
-            c = (int)((off / 8) % C);
-            const int slot = 8 * kg + jj, g32 = slot >> 5, q = (slot & 31) >> 3, j8 = slot & 7;
-            n = j * NC + 32 * g32 + (j8 < 4 ? 4 * q + j8 : 16 + 4 * q + (j8 - 4));
+            const int cp = (int)((off / 8) % C);  // row position -> output column, same rule: the lane's pair of tiles = 8 columns
+            c = (cp & ~31) + 8 * ((cp >> 2) & 3) + 4 * ((cp >> 4) & 1) + (cp & 3);
+            n = j * NC + 8 * kg + jj;             // k slot 8q + j  <->  hidden unit 8q + j (see above): natural order
         }
         float v = pp.w2_like ? pp.src[(long)c * H4 + n] : pp.src[(long)n * C + c];
         if (pp.scale) v *= pp.scale[c];
@@ -185,9 +191,9 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 // accumulators start from the bias (lane owns 4 consecutive hidden columns of its rows)
-                const int n0 = ch * NC + sub * 32 + 4 * lg;
+                const int n0 = ch * NC + sub * 32 + 8 * lg;        // this lane's 8 consecutive hidden units
                 const f32x4 bia0 = *reinterpret_cast<const f32x4*>(s_b1 + n0);
-                const f32x4 bia1 = *reinterpret_cast<const f32x4*>(s_b1 + n0 + 16);
+                const f32x4 bia1 = *reinterpret_cast<const f32x4*>(s_b1 + n0 + 4);
                 f32x4 hacc[MT][2];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) { hacc[mi][0] = bia0; hacc[mi][1] = bia1; }
@@ -208,9 +214,8 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
                     if (SAVE) {
                         const long row = row0 + 16 * mi;
                         if (row < p.M) {
-                            bf16_t* hp = p.hpre + row * (4 * C) + n0;
-                            *reinterpret_cast<uint2*>(hp) = make_uint2(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]));
-                            *reinterpret_cast<uint2*>(hp + 16) = make_uint2(pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3]));
+                            *reinterpret_cast<uint4*>(p.hpre + row * (4 * C) + n0) =
+                                make_uint4(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]), pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3]));
                         }
                     }
                     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -232,17 +237,24 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
         for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
             if (row < p.M) {
-                uint2 rv[CT];
+                // c-tile pair (2j, 2j+1) of this lane = columns 32j + 8 lg .. +7
+                uint4 rv[CT / 2];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) rv[ct] = *reinterpret_cast<const uint2*>(p.res + row * C + ct * 16 + 4 * lg);
+                for (int j = 0; j < CT / 2; ++j) rv[j] = *reinterpret_cast<const uint4*>(p.res + row * C + 32 * j + 8 * lg);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const f32x4 b2 = *reinterpret_cast<const f32x4*>(s_b2 + ct * 16 + 4 * lg);
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_gm + ct * 16 + 4 * lg);
-                    const f32x4 a = yacc[mi][ct];
-                    const float o0 = fmaf(gm[0], a[0] + b2[0], bf2f_lo(rv[ct].x)), o1 = fmaf(gm[1], a[1] + b2[1], bf2f_hi(rv[ct].x));
-                    const float o2 = fmaf(gm[2], a[2] + b2[2], bf2f_lo(rv[ct].y)), o3 = fmaf(gm[3], a[3] + b2[3], bf2f_hi(rv[ct].y));
-                    *reinterpret_cast<uint2*>(p.y + row * C + ct * 16 + 4 * lg) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+                for (int j = 0; j < CT / 2; ++j) {
+                    const int c8 = 32 * j + 8 * lg;
+                    const unsigned rw[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+                    unsigned o[4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 b2 = *reinterpret_cast<const f32x4*>(s_b2 + c8 + 4 * h);
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(s_gm + c8 + 4 * h);
+                        const f32x4 a = yacc[mi][2 * j + h];
+                        o[2 * h] = pack2bf(fmaf(gm[0], a[0] + b2[0], bf2f_lo(rw[2 * h])), fmaf(gm[1], a[1] + b2[1], bf2f_hi(rw[2 * h])));
+                        o[2 * h + 1] = pack2bf(fmaf(gm[2], a[2] + b2[2], bf2f_lo(rw[2 * h + 1])), fmaf(gm[3], a[3] + b2[3], bf2f_hi(rw[2 * h + 1])));
+                    }
+                    *reinterpret_cast<uint4*>(p.y + row * C + c8) = make_uint4(o[0], o[1], o[2], o[3]);
                 }
             }
         }
@@ -379,9 +391,9 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
             const char* wb = smem + (ch & 1) * CHUNK;
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
-                const int n0 = ch * NC + sub * 32 + 4 * lg;
+                const int n0 = ch * NC + sub * 32 + 8 * lg;        // this lane's 8 consecutive hidden units
                 const f32x4 bia0 = *reinterpret_cast<const f32x4*>(s_b1 + n0);
-                const f32x4 bia1 = *reinterpret_cast<const f32x4*>(s_b1 + n0 + 16);
+                const f32x4 bia1 = *reinterpret_cast<const f32x4*>(s_b1 + n0 + 4);
                 f32x4 hacc[MT][2], gacc[MT][2];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
@@ -390,10 +402,9 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                     } else {             // saved pre-activation (bias already in it): lane = row, 4 consecutive columns
                         const long row = row0 + 16 * mi;
                         const long rr = row < p.M ? row : p.M - 1;
-                        const bf16_t* hq = p.hpre + rr * (4 * C) + n0;
-                        const uint2 u0 = *reinterpret_cast<const uint2*>(hq), u1 = *reinterpret_cast<const uint2*>(hq + 16);
-                        hacc[mi][0] = f32x4{bf2f_lo(u0.x), bf2f_hi(u0.x), bf2f_lo(u0.y), bf2f_hi(u0.y)};
-                        hacc[mi][1] = f32x4{bf2f_lo(u1.x), bf2f_hi(u1.x), bf2f_lo(u1.y), bf2f_hi(u1.y)};
+                        const uint4 u = *reinterpret_cast<const uint4*>(p.hpre + rr * (4 * C) + n0);
+                        hacc[mi][0] = f32x4{bf2f_lo(u.x), bf2f_hi(u.x), bf2f_lo(u.y), bf2f_hi(u.y)};
+                        hacc[mi][1] = f32x4{bf2f_lo(u.z), bf2f_hi(u.z), bf2f_lo(u.w), bf2f_hi(u.w)};
                     }
                     gacc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; gacc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -433,12 +444,8 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                     dhf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{dp[0], dp[1], dp[2], dp[3]}));
                     const long row = row0 + 16 * mi;
                     if (row < p.M) {
-                        bf16_t* gq = p.g + row * (4 * C) + n0;
-                        bf16_t* dq = p.dh + row * (4 * C) + n0;
-                        *reinterpret_cast<uint2*>(gq) = make_uint2(gp[0], gp[1]);
-                        *reinterpret_cast<uint2*>(gq + 16) = make_uint2(gp[2], gp[3]);
-                        *reinterpret_cast<uint2*>(dq) = make_uint2(dp[0], dp[1]);
-                        *reinterpret_cast<uint2*>(dq + 16) = make_uint2(dp[2], dp[3]);
+                        *reinterpret_cast<uint4*>(p.g + row * (4 * C) + n0) = make_uint4(gp[0], gp[1], gp[2], gp[3]);
+                        *reinterpret_cast<uint4*>(p.dh + row * (4 * C) + n0) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
                     }
                 }
 #pragma unroll
@@ -456,9 +463,10 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                 const long row = row0 + 16 * mi;
                 if (row < p.M) {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        const f32x4 a = dxacc[mi][ct];
-                        *reinterpret_cast<uint2*>(p.dxln + row * C + ct * 16 + 4 * lg) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+                    for (int j = 0; j < CT / 2; ++j) {
+                        const f32x4 a = dxacc[mi][2 * j], b = dxacc[mi][2 * j + 1];
+                        *reinterpret_cast<uint4*>(p.dxln + row * C + 32 * j + 8 * lg) =
+                            make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3]));
                     }
                 }
             }
@@ -472,11 +480,11 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                 const long row = row0 + 16 * mi;
                 const long rr = row < p.M ? row : p.M - 1;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) xv[mi][ct] = *reinterpret_cast<const uint2*>(p.xd + rr * C + ct * 16 + 4 * lg);
+                for (int ct = 0; ct < CT; ++ct) xv[mi][ct] = *reinterpret_cast<const uint2*>(p.xd + rr * C + 32 * (ct >> 1) + 8 * lg + 4 * (ct & 1));
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + ct * 16 + 4 * lg);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + 32 * (ct >> 1) + 8 * lg + 4 * (ct & 1));
                     const float x[4] = {bf2f_lo(xv[mi][ct].x), bf2f_hi(xv[mi][ct].x), bf2f_lo(xv[mi][ct].y), bf2f_hi(xv[mi][ct].y)};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -491,7 +499,8 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + ct * 16 + 4 * lg);
+                const int cc = 32 * (ct >> 1) + 8 * lg + 4 * (ct & 1);       // this lane's 4 columns of tile ct
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + cc);
                 float cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
@@ -506,12 +515,12 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                         o[r] = row_rstd[mi] * (fmaf(-xh, m2[mi], dv * gm[r]) - m1[mi]);
                         cg[r] = fmaf(dv, xh, cg[r]); cb[r] += dv;
                     }
-                    if (ok) *reinterpret_cast<uint2*>(p.dxln + row * C + ct * 16 + 4 * lg) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                    if (ok) *reinterpret_cast<uint2*>(p.dxln + row * C + cc) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float tg = row16_sum(cg[r]), tb = row16_sum(cb[r]);
-                    if (li == 0) { atomicAdd(s_dg + ct * 16 + 4 * lg + r, tg); atomicAdd(s_db + ct * 16 + 4 * lg + r, tb); }
+                    if (li == 0) { atomicAdd(s_dg + cc + r, tg); atomicAdd(s_db + cc + r, tb); }
                 }
             }
         }
