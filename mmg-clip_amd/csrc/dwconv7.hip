@@ -227,7 +227,7 @@ MMG_API int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, c
     // MMG_DWCONV_MFMA=1 selects the matrix-core formulation (dwconv7_mfma.hip: correct, not faster yet); default is the fp32
     // VALU kernel below
     static const int use_mfma = getenv("MMG_DWCONV_MFMA") ? atoi(getenv("MMG_DWCONV_MFMA")) : 0;
-    if (use_mfma && n > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0 && C / 16 <= 65535) {
+    if (use_mfma && n > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0) {
         const int rc = dwconv7_mfma_launch(x, w, bias, add, y, n, H, W, C, flip, stream);
         if (rc) mmg_set_error("mmg_dwconv7_nhwc: launch failed");
         return rc;
