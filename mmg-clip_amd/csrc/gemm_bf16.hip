@@ -419,16 +419,17 @@ __device__ __forceinline__ int tn_swz(int m, int c) {
 }
 
 // rows m (reduction) x 128 columns (col0.., clamped) -> lane-linear LDS tile, swizzled on the source side
+template <int BK>
 __device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ G, int ld, int m0, int M, int col0, int ncols,
                                          char* lds_tile, int tid) {
 #pragma unroll
-    for (int it = 0; it < (TN_BK * 16) / GEMM_THREADS; ++it) {
+    for (int it = 0; it < (BK * 16) / GEMM_THREADS; ++it) {
         const int p = it * GEMM_THREADS + tid;
         const int r = p >> 4, s = p & 15;
         // tn_swz is an involution in c for fixed m: logical chunk stored at physical slot s
         const int c = tn_swz(r, s);
         const int gm = min(m0 + r, M - 1);
-        const int gc = min(col0 + c * 8, ncols - 8);
+        const int gc = max(min(col0 + c * 8, ncols - 8), 0);
         glds16(G + (size_t)gm * ld + gc, lds_tile + (size_t)(it * GEMM_THREADS + (tid & ~63)) * 16);
     }
 }
@@ -446,12 +447,19 @@ __device__ __forceinline__ bf16x8 read_frag_tr(const char* lds_tile, int mk, int
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// Output tile (128*K1) x (128*K2), 2 x 2 waves, each wave (4*K1) x (4*K2) fragments; (K1, K2) in {(1,1), (1,2), (2,1)}.
+// Why the 256-wide variants: every tile of the WIDE operand re-reads the whole narrow operand for its chunk of rows
+// (measured: 2.5x the algorithmic bytes left the L2s, and the step as a whole runs at ~4 TB/s of HBM traffic), so halving the
+// number of wide tiles removes a third of the traffic of the ConvNeXt stage-2/3 shapes.  Their stages are 32 rows (24 KiB)
+// so that two independent workgroups still share a CU (one 8-wave workgroup per CU ran in lockstep on the stage barrier and
+// was no faster).
+template <int K1, int K2, int BK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const GemmTN g) {
-    constexpr int TILE_BYTES = TN_BK * TN_T * 2;   // 16 KiB
-    constexpr int LDCS = TN_T + 4;
+    constexpr int FM = 4 * K1, FN = 4 * K2;
+    constexpr int SUB = BK * TN_T * 2;               // one 128-column image of a stage
+    constexpr int STAGE = (K1 + K2) * SUB;
+    constexpr int T1 = K1 * TN_T, T2 = K2 * TN_T, LDCS = T2 + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#define TN_AS(s) (smem + (s) * 2 * TILE_BYTES)
-#define TN_BS(s) (smem + (s) * 2 * TILE_BYTES + TILE_BYTES)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int w1 = wave >> 1, w2 = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
@@ -475,89 +483,144 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(const GemmTN g
         chunk = blockIdx.y;
         t1 = tile / g.tiles2; t2 = tile - t1 * g.tiles2;
     }
-    const int c1 = t1 * TN_T, c2 = t2 * TN_T;
+    const int c1 = t1 * T1, c2 = t2 * T2;
     const int m_begin = chunk * g.rows_per_chunk;
     const int m_end = min(m_begin + g.rows_per_chunk, g.M);
     if (m_begin >= m_end) return;
 
-    f32x4 acc[4][4];
+    // fragments wholly beyond N1 / N2 (tile wider than the matrix) are skipped: wave-uniform predicates
+    bool a_on[FM], b_on[FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i) a_on[i] = c1 + (w1 * FM + i) * 16 < g.N1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) b_on[j] = c2 + (w2 * FN + j) * 16 < g.N2;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // bias gradient: one extra MFMA per A fragment against an all-ones operand gives the column sums of A in every
     // accumulator row; only the workgroups of the first N2 tile (and their w2 == 0 waves) do it.
     const bool do_colsum = (g.colsum_a != nullptr) && (t2 == 0) && (w2 == 0);
-    f32x4 accb[4];
+    f32x4 accb[FM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < FM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const short one_bf = (short)0x3F80;
     const bf16x8 ones = {one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
 
-    const int nk = (m_end - m_begin + TN_BK - 1) / TN_BK;
-    stage_tn(g.A, g.lda, m_begin, g.M, c1, g.N1, TN_AS(0), tid);
-    stage_tn(g.B, g.ldb, m_begin, g.M, c2, g.N2, TN_BS(0), tid);
+    auto stage = [&](int buf, int m0) {
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int k = 0; k < K1; ++k) stage_tn<BK>(g.A, g.lda, m0, g.M, c1 + k * TN_T, g.N1, base + k * SUB, tid);
+#pragma unroll
+        for (int k = 0; k < K2; ++k) stage_tn<BK>(g.B, g.ldb, m0, g.M, c2 + k * TN_T, g.N2, base + (K1 + k) * SUB, tid);
+    };
+
+    const int nk = (m_end - m_begin + BK - 1) / BK;
+    stage(0, m_begin);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = kt & 1;
-        const int mt = m_begin + kt * TN_BK;
-        if (mt + TN_BK > m_end) {
+        const int mt = m_begin + kt * BK;
+        char* cbase = smem + cur * STAGE;
+        if (mt + BK > m_end) {
             // ragged end of the reduction: rows >= m_end must contribute zero (they hold clamped duplicates)
-            const int valid = m_end - mt;
-            for (int p = tid; p < (TN_BK - valid) * 16; p += GEMM_THREADS) {
-                const int r = valid + (p >> 4), s = p & 15;
-                *reinterpret_cast<uint4*>(TN_AS(cur) + r * 256 + s * 16) = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(TN_BS(cur) + r * 256 + s * 16) = make_uint4(0, 0, 0, 0);
+            const int valid = m_end - mt, per = (BK - valid) * 16;
+            for (int p = tid; p < per * (K1 + K2); p += GEMM_THREADS) {
+                const int img = p / per, q = p - img * per;
+                *reinterpret_cast<uint4*>(cbase + img * SUB + (valid + (q >> 4)) * 256 + (q & 15) * 16) = make_uint4(0, 0, 0, 0);
             }
             __syncthreads();
         }
-        if (kt + 1 < nk) {
-            stage_tn(g.A, g.lda, mt + TN_BK, g.M, c1, g.N1, TN_AS(cur ^ 1), tid);
-            stage_tn(g.B, g.ldb, mt + TN_BK, g.M, c2, g.N2, TN_BS(cur ^ 1), tid);
-        }
+        if (kt + 1 < nk) stage(cur ^ 1, mt + BK);
 #pragma unroll
-        for (int ks = 0; ks < TN_BK / 32; ++ks) {
-            bf16x8 af[4], bfr[4];
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[FM], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag_tr(TN_AS(cur), ks * 32, w1 * 4 + i, lane);
+            for (int i = 0; i < FM; ++i) {
+                const int cb = w1 * FM + i;
+                af[i] = read_frag_tr(cbase + (cb >> 3) * SUB, ks * 32, cb & 7, lane);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = read_frag_tr(TN_BS(cur), ks * 32, w2 * 4 + j, lane);
+            for (int j = 0; j < FN; ++j) {
+                const int cb = w2 * FN + j;
+                bfr[j] = read_frag_tr(cbase + (K1 + (cb >> 3)) * SUB, ks * 32, cb & 7, lane);
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FM; ++i) {
+                if (a_on[i]) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FN; ++j)
+                        if (b_on[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+            }
             if (do_colsum) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+                for (int i = 0; i < FM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
             }
         }
     }
     if (do_colsum && lg == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n1 = c1 + w1 * 64 + i * 16 + li;
+        for (int i = 0; i < FM; ++i) {
+            const int n1 = c1 + (w1 * FM + i) * 16 + li;
             if (n1 < g.N1) atomicAdd(g.colsum_a + n1, accb[i][0] * g.alpha);
         }
     }
-    __syncthreads();
-    // swapped issue: lane (li, lg) holds C[n1 = .. + li][n2 = .. + 4 lg + 0..3]
-    float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = w1 * 64 + i * 16 + li;
-            const int c = w2 * 64 + j * 16 + 4 * lg;
-            *reinterpret_cast<f32x4*>(Cs + r * LDCS + c) = acc[i][j];
-        }
-    __syncthreads();
+    // swapped issue: lane (li, lg) holds C[n1 = .. + li][n2 = .. + 4 lg + 0..3]; 64-row slabs go through LDS and leave as
     // 256-byte contiguous atomic rows (one wave instruction = 64 consecutive floats)
-    for (int idx = tid; idx < TN_T * TN_T; idx += GEMM_THREADS) {
-        const int r = idx >> 7, c = idx & 127;
-        const int gr = c1 + r, gc = c2 + c;
-        if (gr < g.N1 && gc < g.N2) atomicAdd(g.C + (size_t)gr * g.ldc + gc, Cs[r * LDCS + c] * g.alpha);
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int SLABS = T1 / 64, SPW = FM / 4;                 // slabs per tile, slabs per wave row
+#pragma unroll
+    for (int sl = 0; sl < SLABS; ++sl) {
+        __syncthreads();
+        if (sl / SPW == w1) {
+            const int i0 = (sl % SPW) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    *reinterpret_cast<f32x4*>(Cs + (i * 16 + li) * LDCS + (w2 * FN + j) * 16 + 4 * lg) = acc[i0 + i][j];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 64 * T2; idx += GEMM_THREADS) {
+            const int r = idx / T2, c = idx - r * T2;
+            const int gr = c1 + sl * 64 + r, gc = c2 + c;
+            if (gr < g.N1 && gc < g.N2) atomicAdd(g.C + (size_t)gr * g.ldc + gc, Cs[r * LDCS + c] * g.alpha);
+        }
+    }
+}
+
+template <int K1, int K2, int BK>
+static void launch_tn(GemmTN& g, hipStream_t stream) {
+    static const int target_wgs = getenv("MMG_TN_WGS") ? atoi(getenv("MMG_TN_WGS")) : 512;
+    static const int xcd = getenv("MMG_TN_XCD") ? atoi(getenv("MMG_TN_XCD")) : 1;
+    g.tiles1 = cdiv(g.N1, K1 * TN_T);
+    g.tiles2 = cdiv(g.N2, K2 * TN_T);
+    const int tiles = g.tiles1 * g.tiles2;
+    int chunks = target_wgs / tiles;
+    if (chunks < 1) chunks = 1;
+    const int max_chunks = cdiv(g.M, 64);
+    if (chunks > max_chunks) chunks = max_chunks;
+    g.rows_per_chunk = cdiv(cdiv(g.M, chunks), 64) * 64;
+    chunks = cdiv(g.M, g.rows_per_chunk);
+    g.chunks = chunks;
+    g.xcd_order = xcd ? (g.N2 >= g.N1 ? 1 : 2) : 0;
+    if (g.xcd_order) {       // whole groups per XCD: fall back when that would overfill an XCD's share of the workgroup budget
+        const int G = g.xcd_order == 1 ? g.tiles1 : g.tiles2, ngroups = (tiles / G) * chunks;
+        if (((ngroups + 7) / 8) * G * 8 > target_wgs && tiles * chunks <= target_wgs) g.xcd_order = 0;
+    }
+    const size_t stage = 2 * (size_t)(K1 + K2) * (BK * TN_T * 2);
+    const size_t cs = (size_t)64 * (K2 * TN_T + 4) * 4;
+    const size_t shm = stage > cs ? stage : cs;
+    mmg_allow_lds(gemm_tn_kernel<K1, K2, BK>, shm);
+    if (g.xcd_order) {
+        const int G = g.xcd_order == 1 ? g.tiles1 : g.tiles2, ngroups = (tiles / G) * chunks;
+        hipLaunchKernelGGL((gemm_tn_kernel<K1, K2, BK>), dim3(8 * ((ngroups + 7) / 8) * G), dim3(GEMM_THREADS), shm, stream, g);
+    } else {
+        hipLaunchKernelGGL((gemm_tn_kernel<K1, K2, BK>), dim3(tiles, chunks), dim3(GEMM_THREADS), shm, stream, g);
     }
 }
 
@@ -571,32 +634,13 @@ MMG_API int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, flo
     GemmTN g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N1 = N1; g.N2 = N2; g.lda = lda; g.ldb = ldb;
     g.C = C; g.ldc = ldc; g.alpha = alpha; g.colsum_a = colsum_a;
-    g.tiles1 = cdiv(N1, TN_T);
-    g.tiles2 = cdiv(N2, TN_T);
-    const int tiles = g.tiles1 * g.tiles2;
-    static const int target_wgs = getenv("MMG_TN_WGS") ? atoi(getenv("MMG_TN_WGS")) : 512;
-    static const int xcd = getenv("MMG_TN_XCD") ? atoi(getenv("MMG_TN_XCD")) : 1;
-    int chunks = target_wgs / tiles;
-    if (chunks < 1) chunks = 1;
-    const int max_chunks = cdiv(M, TN_BK);
-    if (chunks > max_chunks) chunks = max_chunks;
-    g.rows_per_chunk = cdiv(cdiv(M, chunks), TN_BK) * TN_BK;
-    chunks = cdiv(M, g.rows_per_chunk);
-    g.chunks = chunks;
-    g.xcd_order = xcd ? (N2 >= N1 ? 1 : 2) : 0;
-    if (g.xcd_order) {       // whole groups per XCD: fall back when that would overfill an XCD's share of the workgroup budget
-        const int G = g.xcd_order == 1 ? g.tiles1 : g.tiles2, ngroups = (tiles / G) * chunks;
-        if (((ngroups + 7) / 8) * G * 8 > target_wgs && tiles * chunks <= target_wgs) g.xcd_order = 0;
-    }
-    const size_t stage = 4 * (size_t)(TN_BK * TN_T * 2);
-    const size_t cs = (size_t)TN_T * (TN_T + 4) * 4;
-    const size_t shm = stage > cs ? stage : cs;
-    mmg_allow_lds(gemm_tn_kernel, shm);
-    if (g.xcd_order) {
-        const int G = g.xcd_order == 1 ? g.tiles1 : g.tiles2, ngroups = (tiles / G) * chunks;
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(8 * ((ngroups + 7) / 8) * G), dim3(GEMM_THREADS), shm, stream, g);
-    }
-    else hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, chunks), dim3(GEMM_THREADS), shm, stream, g);
+    // 256-wide tiles on the wider side when it is a multiple of 256 (measured: -6...-19 % on the ConvNeXt shapes, slower on
+    // the short BERT reductions where the tile count is what fills the GPU); MMG_TN_WIDE=0 disables
+    static const int wide = getenv("MMG_TN_WIDE") ? atoi(getenv("MMG_TN_WIDE")) : 1;
+    const bool long_m = M >= 32768;
+    if (wide && long_m && N2 >= N1 && N2 % 256 == 0) launch_tn<1, 2, 32>(g, stream);
+    else if (wide && long_m && N1 > N2 && N1 % 256 == 0) launch_tn<2, 1, 32>(g, stream);
+    else launch_tn<1, 1, 64>(g, stream);
     MMG_LAUNCH_CHECK("mmg_gemm_tn_bf16");
     return 0;
 }

@@ -75,7 +75,7 @@ def test_tn_integer_exact_asymmetric(dev):
     assert torch.equal(out.cpu(), a.t() @ b)
 
 
-@pytest.mark.parametrize("M,N1,N2", [(256, 128, 128), (4096, 384, 96), (8192, 96, 384), (1000, 200, 72), (37, 512, 768),
+@pytest.mark.parametrize("M,N1,N2", [(256, 128, 128), (4096, 384, 96), (8192, 96, 384), (1000, 200, 72), (37, 512, 768), (33000, 192, 768), (32800, 512, 128),
                                      (19712, 768, 3072), (65536, 192, 768)])
 def test_tn(dev, M, N1, N2):
     from mmgclip import linalg
