@@ -32,18 +32,19 @@ def _randomize(module, seed):
                 p.mul_(2.5)
 
 
-@pytest.mark.parametrize("size,n", [(64, 3), (96, 2)])
-def test_convnext_tower_forward_backward(dev, size, n):
-    from mmgclip.networks.encoder import ConvNextTinyEncoder
+@pytest.mark.parametrize("size,n,variant", [(64, 3, "tiny"), (96, 2, "tiny"), (64, 2, "base")])
+def test_convnext_tower_forward_backward(dev, size, n, variant):
+    """tiny: fused CNBlock kernels at C = 96 / 192 / 384 (+ GEMM pair at 768); base: C = 128 / 256 fused, 512 / 1024 GEMM pair."""
+    from mmgclip.networks.encoder import ConvNextBaseEncoder, ConvNextTinyEncoder
     torch.manual_seed(0)
-    tower = ConvNextTinyEncoder(micro_batch=2)
+    tower = (ConvNextTinyEncoder if variant == "tiny" else ConvNextBaseEncoder)(micro_batch=2)
     _randomize(tower, 1)
     sd = {k[len("model."):]: v.clone() for k, v in tower.state_dict().items()}
     img = torch.rand(n, 1, size, size, generator=torch.Generator().manual_seed(2))
-    wgt = torch.randn(n, 768, generator=torch.Generator().manual_seed(3))
+    wgt = torch.randn(n, tower.model_output_dimension, generator=torch.Generator().manual_seed(3))
     # oracle
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    pooled, _ = E.convnext_forward(osd, img)
+    pooled, _ = E.convnext_forward(osd, img, depths=(3, 3, 9, 3) if variant == "tiny" else (3, 3, 27, 3))
     (pooled.flatten(1) * wgt).sum().backward()
     # device
     tower = tower.to(dev)
