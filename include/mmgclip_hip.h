@@ -227,6 +227,16 @@ int mmg_attention_long_bwd(const void* qkv, int ld, const long long* mask, const
                            const void* dctx, int lddc, void* dqkv, int lddq, float* delta_ws, int B, int S, int heads,
                            int Hd, float scale, mmg_stream_t stream);
 
+/* The same attention on the packed ("unpadded") layout: sequence b occupies rows cu_seqlens[b] .. cu_seqlens[b+1] of qkv / ctx /
+ * dctx / dqkv (int32 [B+1], device), every token attended, lengths in [1, S_max]; lse is [B, heads, S_max].  The reference pads
+ * every prompt to max_length (mmgclip/dataset/dataset.py:347) and reads only the [SEP] row (mmgclip_model.py:110-111): the
+ * text tower runs on the valid tokens only and scatters its last hidden state back into the padded layout. */
+int mmg_attention_varlen_fwd(const void* qkv, int ld, const int* cu_seqlens, void* ctx, int ldc, float* lse, int B, int S_max,
+                             int heads, int Hd, float scale, mmg_stream_t stream);
+int mmg_attention_varlen_bwd(const void* qkv, int ld, const int* cu_seqlens, const void* ctx, int ldc, const float* lse,
+                             const void* dctx, int lddc, void* dqkv, int lddq, int B, int S_max, int heads, int Hd,
+                             float scale, mmg_stream_t stream);
+
 /* out[m,:] = word[ids[m]] + pos[m % S] + type[type_ids[m]] (bf16 tables [V|P|T, H]); HF BertEmbeddings before its
  * LayerNorm (mmgclip/networks/encoder.py:156). */
 int mmg_bert_embed_fwd(const long long* ids, const long long* type_ids, const void* word, const void* pos,

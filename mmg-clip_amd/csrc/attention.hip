@@ -66,7 +66,8 @@ struct AttArgs {
     const long long* mask;              // [B,S] 1 = attend, 0 = padding (nullable)
     bf16_t* ctx; int ldc;               // [B*S, Hd]
     float* lse;                         // [B, heads, S]
-    int S, S_pad, heads, Hd;
+    int S, S_pad, heads, Hd;             // S = row stride of a sequence (padded layout) / longest sequence (packed layout)
+    const int* cu;                      // nullable: packed layout, sequence b = rows cu[b] .. cu[b+1] (all attended)
     float scale;
     // backward
     const bf16_t* dctx; int lddc;       // [B*S, Hd]
@@ -81,19 +82,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttArgs a) {
     char* Vs = smem + a.S_pad * 128;
     float* madd = reinterpret_cast<float*>(smem + 2 * a.S_pad * 128);
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int S = a.cu ? a.cu[b + 1] - a.cu[b] : a.S;                        // this sequence's length
+    const size_t row0 = a.cu ? (size_t)a.cu[b] : (size_t)b * a.S;            // its first row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
-    att_stage(base + a.Hd, a.ld, Ks, a.S, a.S_pad);
-    att_stage(base + 2 * a.Hd, a.ld, Vs, a.S, a.S_pad);
+    const bf16_t* base = a.qkv + row0 * a.ld + h * ATT_D;
+    att_stage(base + a.Hd, a.ld, Ks, S, a.S_pad);
+    att_stage(base + 2 * a.Hd, a.ld, Vs, S, a.S_pad);
     for (int k = threadIdx.x; k < a.S_pad; k += 256)
-        madd[k] = (k < a.S && (!a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
+        madd[k] = (k < S && (a.cu || !a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
     __syncthreads();
 
     const int ntile = a.S_pad / 16;
     for (int qt = wave; qt < ntile; qt += 4) {
         const int q0 = qt * 16;
-        const int qrow = min(q0 + li, a.S - 1);
+        const int qrow = min(q0 + li, S - 1);
         bf16x8 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -142,8 +145,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttArgs a) {
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Vs, c * 32, dt, lane), pf, o[dt], 0, 0, 0);
             }
         }
-        if (q0 + li < a.S) {
-            bf16_t* dst = a.ctx + ((size_t)b * a.S + q0 + li) * a.ldc + h * ATT_D + 4 * g;
+        if (q0 + li < S) {
+            bf16_t* dst = a.ctx + (row0 + q0 + li) * a.ldc + h * ATT_D + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 v;
@@ -170,24 +173,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttArgs a) {
     float* lses = madd + a.S_pad;                                    // [S_pad]
     float* delta = lses + a.S_pad;                                   // [S_pad] rowsum(dO * O)
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int S = a.cu ? a.cu[b + 1] - a.cu[b] : a.S;                        // this sequence's length
+    const size_t row0 = a.cu ? (size_t)a.cu[b] : (size_t)b * a.S;            // its first row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
-    const bf16_t* gbase = a.dctx + (size_t)b * a.S * a.lddc + h * ATT_D;
-    const bf16_t* obase = a.ctx + (size_t)b * a.S * a.ldc + h * ATT_D;
-    att_stage(base, a.ld, Qs, a.S, a.S_pad);
-    att_stage(base + a.Hd, a.ld, Ks, a.S, a.S_pad);
-    att_stage(base + 2 * a.Hd, a.ld, Vs, a.S, a.S_pad);
-    att_stage(gbase, a.lddc, Gs, a.S, a.S_pad);
+    const bf16_t* base = a.qkv + row0 * a.ld + h * ATT_D;
+    const bf16_t* gbase = a.dctx + row0 * a.lddc + h * ATT_D;
+    const bf16_t* obase = a.ctx + row0 * a.ldc + h * ATT_D;
+    att_stage(base, a.ld, Qs, S, a.S_pad);
+    att_stage(base + a.Hd, a.ld, Ks, S, a.S_pad);
+    att_stage(base + 2 * a.Hd, a.ld, Vs, S, a.S_pad);
+    att_stage(gbase, a.lddc, Gs, S, a.S_pad);
     for (int k = threadIdx.x; k < a.S_pad; k += 256) {
-        madd[k] = (k < a.S && (!a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
-        lses[k] = k < a.S ? a.lse[((size_t)b * a.heads + h) * a.S + k] : 1.0e30f;
+        madd[k] = (k < S && (a.cu || !a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
+        lses[k] = k < S ? a.lse[((size_t)b * a.heads + h) * a.S + k] : 1.0e30f;
     }
     // delta[q] = sum_d dO[q,d] * O[q,d] : 4 lanes per row, 16 columns each
     for (int idx = threadIdx.x; idx < a.S_pad * 4; idx += 256) {
         const int r = idx >> 2, part = idx & 3;
         float s = 0.f;
-        if (r < a.S) {
+        if (r < S) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const uint4 gv = *reinterpret_cast<const uint4*>(gbase + (size_t)r * a.lddc + part * 16 + c * 8);
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttArgs a) {
             for (int dt = 0; dt < 4; ++dt)
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Ks, c * 32, dt, lane), dsf, dq[dt], 0, 0, 0);
         }
-        if (q0 + li < a.S) {
-            bf16_t* dst = a.dqkv + ((size_t)b * a.S + q0 + li) * a.lddq + h * ATT_D + 4 * g;
+        if (q0 + li < S) {
+            bf16_t* dst = a.dqkv + (row0 + q0 + li) * a.lddq + h * ATT_D + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 v;
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttArgs a) {
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Qs, c * 32, dt, lane), dsf, dk[dt], 0, 0, 0);
             }
         }
-        if (k0 + li < a.S) {
-            bf16_t* dst = a.dqkv + ((size_t)b * a.S + k0 + li) * a.lddq + h * ATT_D + 4 * g;
+        if (k0 + li < S) {
+            bf16_t* dst = a.dqkv + (row0 + k0 + li) * a.lddq + h * ATT_D + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 v;
@@ -345,6 +350,51 @@ MMG_API int mmg_attention_bwd(const void* qkv, int ld, const long long* mask, co
     mmg_allow_lds(attn_bwd_kernel, shm);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), shm, stream, a);
     MMG_LAUNCH_CHECK("mmg_attention_bwd");
+    return 0;
+}
+
+// Packed ("unpadded") layout: the B sequences are stored back to back, sequence b in rows cu_seqlens[b] .. cu_seqlens[b+1]
+// (int32 [B+1] on the device), every token attended; S_max bounds the lengths (LDS sizing, lse stride [B, heads, S_max]).
+// The reference pads every prompt to max_length (mmgclip/dataset/dataset.py:347) and only reads the [SEP] position
+// (mmgclip_model.py:110-111), so the padded rows are pure overhead for the tower.
+MMG_API int mmg_attention_varlen_fwd(const void* qkv, int ld, const int* cu_seqlens, void* ctx, int ldc, float* lse, int B,
+                                     int S_max, int heads, int Hd, float scale, hipStream_t stream) {
+    if (att_check("mmg_attention_varlen_fwd", B, S_max, heads, Hd, ld, 512)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && cu_seqlens && ldc >= Hd && ldc % 8 == 0, "mmg_attention_varlen_fwd: bad pointer or ldc");
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.cu = cu_seqlens; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = lse;
+    a.S = S_max; a.S_pad = cdiv(S_max, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    const size_t shm = (size_t)2 * a.S_pad * 128 + a.S_pad * 4;
+    const dim3 grid(B * heads);
+    const int nt = a.S_pad / 16;
+#define ATT_FWD(NT)                                                                                   \
+    do {                                                                                              \
+        mmg_allow_lds(attn_fwd_kernel<NT>, shm);                                                      \
+        hipLaunchKernelGGL(attn_fwd_kernel<NT>, grid, dim3(256), shm, stream, a);                     \
+    } while (0)
+    if (nt <= 6) ATT_FWD(6);
+    else if (nt <= 8) ATT_FWD(8);
+    else if (nt <= 16) ATT_FWD(16);
+    else ATT_FWD(32);
+#undef ATT_FWD
+    MMG_LAUNCH_CHECK("mmg_attention_varlen_fwd");
+    return 0;
+}
+
+MMG_API int mmg_attention_varlen_bwd(const void* qkv, int ld, const int* cu_seqlens, const void* ctx, int ldc, const float* lse,
+                                     const void* dctx, int lddc, void* dqkv, int lddq, int B, int S_max, int heads, int Hd,
+                                     float scale, hipStream_t stream) {
+    if (att_check("mmg_attention_varlen_bwd", B, S_max, heads, Hd, ld, 256)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && cu_seqlens && ldc >= Hd && lddc >= Hd && lddq >= 3 * Hd && ldc % 8 == 0 &&
+                      lddc % 8 == 0 && lddq % 8 == 0, "mmg_attention_varlen_bwd: bad pointer or leading dimension");
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.cu = cu_seqlens; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = const_cast<float*>(lse);
+    a.S = S_max; a.S_pad = cdiv(S_max, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    a.dctx = (const bf16_t*)dctx; a.lddc = lddc; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
+    const size_t shm = (size_t)4 * a.S_pad * 128 + 3 * a.S_pad * 4;
+    mmg_allow_lds(attn_bwd_kernel, shm);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), shm, stream, a);
+    MMG_LAUNCH_CHECK("mmg_attention_varlen_bwd");
     return 0;
 }
 

@@ -153,19 +153,27 @@ def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None, ln_grads
     return dh, g, xln, dxln, mean, rstd
 
 
-def attention_fwd(qkv, mask, B, S, heads, want_lse=True, force_long=False):
-    """Whole-sequence-in-LDS kernel up to S = 512, flash-style tiled kernel beyond (or when force_long)."""
+def attention_fwd(qkv, mask, B, S, heads, want_lse=True, force_long=False, cu=None):
+    """Whole-sequence-in-LDS kernel up to S = 512, flash-style tiled kernel beyond (or when force_long).
+    cu (int32 [B+1]): packed layout, rows cu[b]..cu[b+1] are sequence b (S = longest sequence, mask unused)."""
     Hd = heads * 64
-    ctx = torch.empty(B * S, Hd, device=qkv.device, dtype=BF16)
+    ctx = torch.empty(qkv.shape[0], Hd, device=qkv.device, dtype=BF16)
     lse = torch.empty(B, heads, S, device=qkv.device, dtype=torch.float32) if want_lse else None
+    if cu is not None:
+        call("mmg_attention_varlen_fwd", ptr(qkv), qkv.stride(0), ptr(cu), ptr(ctx), Hd, ptr(lse), B, S, heads, Hd, 0.125, stream())
+        return ctx, lse
     name = "mmg_attention_long_fwd" if (force_long or S > 512) else "mmg_attention_fwd"
     call(name, ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), Hd, ptr(lse), B, S, heads, Hd, 0.125, stream())
     return ctx, lse
 
 
-def attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, out=None, force_long=False):
+def attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, out=None, force_long=False, cu=None):
     Hd = heads * 64
-    dqkv = out if out is not None else torch.empty(B * S, 3 * Hd, device=qkv.device, dtype=BF16)
+    dqkv = out if out is not None else torch.empty(qkv.shape[0], 3 * Hd, device=qkv.device, dtype=BF16)
+    if cu is not None:
+        call("mmg_attention_varlen_bwd", ptr(qkv), qkv.stride(0), ptr(cu), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),
+             dctx.stride(0), ptr(dqkv), dqkv.stride(0), B, S, heads, Hd, 0.125, stream())
+        return dqkv
     if force_long or S > 256:
         delta = torch.empty(B * heads * S, device=qkv.device, dtype=torch.float32)
         call("mmg_attention_long_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),

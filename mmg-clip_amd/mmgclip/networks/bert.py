@@ -10,6 +10,8 @@ defined for eval()/p = 0 (SURVEY.md §0, §7 "Hard parts").
 Device layout: hidden states bf16 [B*S, 768]; Q, K, V come from ONE fused GEMM ([2304, 768] weight = the three HF
 matrices stacked, contiguous in the parameter arena so its gradient needs no scatter).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -80,6 +82,7 @@ class BertTower(nn.Module):
         self.model.config = self.config
         self.model_output_dimension = self.config.hidden_size
         self.micro_batch = micro_batch        # sequences per pass
+        self.packed = os.environ.get("MMG_BERT_PACKED", "1") != "0"     # run the layers on the valid tokens only
         self._arena = None
         self._wc = None
         self._wc_version = None
@@ -140,18 +143,60 @@ class BertTower(nn.Module):
             assert A.offsets[p + "key.weight"] - A.offsets[p + "query.weight"] == H * H
             assert A.offsets[p + "key.bias"] - A.offsets[p + "query.bias"] == H
 
+    # ---- packed ("unpadded") layout -------------------------------------------------------------------------------
+    @staticmethod
+    def sequence_lengths(mask):
+        """Python list of lengths when `mask` [B,S] is a right-padded prompt batch (ones then zeros, no empty row), else None.
+        Reads the mask on the host: free for a CPU tensor, one small device read otherwise."""
+        m = mask.detach().to("cpu", torch.int64)
+        lens = m.sum(1)
+        S = m.shape[1]
+        if not bool((lens >= 1).all()) or not bool((m == (torch.arange(S)[None, :] < lens[:, None])).all()):
+            return None
+        return lens.tolist()
+
+    def _lengths_of(self, mask):
+        """Lengths of the whole batch, remembered ON the tensor object (so a batch that is fed again costs no device read,
+        and a new or modified tensor can never pick up stale lengths)."""
+        tag = getattr(mask, "_mmg_seq_lens", None)
+        if tag is not None and tag[0] == mask._version:
+            return tag[1]
+        lens = self.sequence_lengths(mask)
+        try:
+            mask._mmg_seq_lens = (mask._version, lens)
+        except Exception:           # noqa: BLE001  (tensor subclasses without attribute support)
+            pass
+        return lens
+
+    def _packing(self, lens, b0, b1, S, device):
+        """(row indices of the valid tokens of sequences b0..b1 inside that slice [T] int64, cu_seqlens int32) or None.
+        The reference pads to max_length (dataset.py:347) and reads only the [SEP] row (mmgclip_model.py:110-111): the layers
+        then run on the valid tokens only."""
+        if lens is None or S > 256:
+            return None
+        sl = lens[b0:b1]
+        if sum(sl) >= len(sl) * S:
+            return None
+        rows = torch.cat([b * S + torch.arange(int(n)) for b, n in enumerate(sl)])
+        cu = torch.zeros(len(sl) + 1, dtype=torch.int32)
+        cu[1:] = torch.tensor(sl, dtype=torch.int32).cumsum(0)
+        return rows.to(device), cu.to(device)
+
     # ---- one micro-batch ---------------------------------------------------------------------------------------
-    def _forward_mb(self, ids, tt, mask, save):
+    def _forward_mb(self, ids, tt, mask, save, pack=None):
         cfg, wc = self.config, self._wc
         B, S = ids.shape
         heads, eps = cfg.num_attention_heads, cfg.layer_norm_eps
         e = self.model.embeddings
         emb = K.bert_embed_fwd(ids, tt, wc["word"], wc["pos"], wc["type"], S)
+        rows, cu = pack if pack is not None else (None, None)
+        if rows is not None:
+            emb = emb.index_select(0, rows)                  # [T, H]: the valid tokens, sequence after sequence
         x, mean, rstd = K.layernorm_fwd(emb, e.LayerNorm.weight.data, e.LayerNorm.bias.data, eps, want_stats=save)
-        saved = {"emb": (emb, mean, rstd), "layers": [], "shape": (B, S), "tok": (ids, tt, mask)} if save else None
+        saved = {"emb": (emb, mean, rstd), "layers": [], "shape": (B, S), "tok": (ids, tt, mask), "pack": pack} if save else None
         for i, lyr in enumerate(self.model.encoder.layer):
             qkv = L.gemm_nt(x, wc[f"{i}.wqkv"], bias=wc[f"{i}.bqkv"][:3 * cfg.hidden_size])
-            ctx, lse = K.attention_fwd(qkv, mask, B, S, heads, want_lse=save)
+            ctx, lse = K.attention_fwd(qkv, mask, B, S, heads, want_lse=save, cu=cu)
             a = L.gemm_nt(ctx, wc[f"{i}.wo"], bias=lyr.attention.output.dense.bias.data, residual=x)
             x1, m1, r1 = K.layernorm_fwd(a, lyr.attention.output.LayerNorm.weight.data, lyr.attention.output.LayerNorm.bias.data,
                                          eps, want_stats=save)
@@ -162,12 +207,19 @@ class BertTower(nn.Module):
             if save:
                 saved["layers"].append((x, qkv, ctx, lse, a, m1, r1, x1, hpre, f, m2, r2))
             x = x2
+        if rows is not None:                                 # back to the padded [B*S, H] layout (padding rows: zeros)
+            full = torch.zeros(B * S, x.shape[1], device=x.device, dtype=x.dtype)
+            full.index_copy_(0, rows, x)
+            x = full
         return x, saved
 
     def _backward_mb(self, dx, saved):
         cfg, wc, A = self.config, self._wc, self._arena
         B, S = saved["shape"]
         ids, tt, mask = saved["tok"]
+        rows, cu = saved["pack"] if saved["pack"] is not None else (None, None)
+        if rows is not None:
+            dx = dx.index_select(0, rows)
         heads, H = cfg.num_attention_heads, cfg.hidden_size
         for i in range(cfg.num_hidden_layers - 1, -1, -1):
             lyr = self.model.encoder.layer[i]
@@ -187,7 +239,7 @@ class BertTower(nn.Module):
             del dx1
             L.gemm_tn_acc(da, ctx, A.g(p + "attention.output.dense.weight"), colsum=A.g(p + "attention.output.dense.bias"))
             dctx = L.gemm_nt(da, wc[f"{i}.wot"])
-            dqkv = K.attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads)
+            dqkv = K.attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, cu=cu)
             del dctx
             gw = A.gspan(p + "attention.self.query.weight", p + "attention.self.value.weight")[:3 * H * H].view(3 * H, H)
             gb = A.gspan(p + "attention.self.query.bias", p + "attention.self.value.bias")[:3 * H]
@@ -199,12 +251,18 @@ class BertTower(nn.Module):
         e = self.model.embeddings
         demb = K.layernorm_bwd(dx, emb, mean, rstd, e.LayerNorm.weight.data, A.g("embeddings.LayerNorm.weight"),
                                A.g("embeddings.LayerNorm.bias"))
+        if rows is not None:
+            full = torch.zeros(B * S, demb.shape[1], device=demb.device, dtype=demb.dtype)
+            full.index_copy_(0, rows, demb)
+            demb = full
         K.bert_embed_bwd(demb, ids, tt, A.g("embeddings.word_embeddings.weight"), A.g("embeddings.position_embeddings.weight"),
                          A.g("embeddings.token_type_embeddings.weight"), B, S)
 
     # ---- public -----------------------------------------------------------------------------------------------------
-    def forward(self, input_ids, attention_mask=None, token_type_ids=None, **_):
-        """-> last_hidden_state as bf16 [B*S, H] (use .view(B, S, H).float() for the HF-shaped tensor)."""
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, packed=None, **_):
+        """-> last_hidden_state as bf16 [B*S, H] (use .view(B, S, H).float() for the HF-shaped tensor).
+        packed=True (default: self.packed) computes the rows of valid tokens only and leaves zeros in the padding rows;
+        packed=False reproduces HF's values there too."""
         _hip.require_gpu(input_ids)
         self._materialize(input_ids.device)
         self._check_qkv_contiguous()
@@ -214,19 +272,23 @@ class BertTower(nn.Module):
         if ids.shape[1] > self.config.max_position_embeddings:
             raise ValueError(f"sequence length {ids.shape[1]} exceeds max_position_embeddings")
         needs_grad = torch.is_grad_enabled() and self._arena.any_trainable()
-        return _BertFn.apply(self, ids, tt, mask, self._anchor if needs_grad else None)
+        use_packed = self.packed if packed is None else bool(packed)
+        lens = self._lengths_of(attention_mask) if (use_packed and attention_mask is not None and ids.shape[1] <= 256) else None
+        return _BertFn.apply(self, ids, tt, mask, self._anchor if needs_grad else None, lens)
 
 
 class _BertFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tower, ids, tt, mask, anchor):
+    def forward(ctx, tower, ids, tt, mask, anchor, lens=None):
         tower._refresh_working_copies()
         save = anchor is not None
         outs, saved = [], []
         mb = tower.micro_batch
         for i in range(0, ids.shape[0], mb):
             sl = slice(i, i + mb)
-            h, sv = tower._forward_mb(ids[sl], tt[sl] if tt is not None else None, mask[sl] if mask is not None else None, save)
+            pack = tower._packing(lens, i, min(i + mb, ids.shape[0]), ids.shape[1], ids.device)
+            h, sv = tower._forward_mb(ids[sl], tt[sl] if tt is not None else None, mask[sl] if mask is not None else None, save,
+                                      pack)
             outs.append(h)
             saved.append(sv)
         ctx.tower, ctx.saved_mb = tower, saved if save else None
@@ -246,7 +308,7 @@ class _BertFn(torch.autograd.Function):
         ctx.saved_mb = None
         if tower.post_backward_hook is not None:
             tower.post_backward_hook(tower._arena)
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class EosPool(torch.autograd.Function):

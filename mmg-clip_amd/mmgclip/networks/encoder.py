@@ -142,11 +142,13 @@ class BertEncoder(BertTower):
             for param in self.model.parameters():
                 param.requires_grad = False
 
-    def hidden_states(self, x):
-        """bf16 [B*S, H] last hidden state (device layout, autograd-connected)."""
-        return BertTower.forward(self, x["input_ids"], x.get("attention_mask"), x.get("token_type_ids"))
+    def hidden_states(self, x, packed=None):
+        """bf16 [B*S, H] last hidden state (device layout, autograd-connected).  By default only the rows of valid tokens are
+        computed (right-padded prompts; padding rows come back as zeros) - all that EOS pooling reads."""
+        return BertTower.forward(self, x["input_ids"], x.get("attention_mask"), x.get("token_type_ids"), packed=packed)
 
     def forward(self, x):
-        """x: mapping with input_ids / attention_mask / token_type_ids -> last_hidden_state fp32 [B,S,H] (encoder.py:156)."""
+        """x: mapping with input_ids / attention_mask / token_type_ids -> last_hidden_state fp32 [B,S,H] (encoder.py:156),
+        padding positions included (HF computes them too)."""
         B, S = x["input_ids"].shape
-        return self.hidden_states(x).float().view(B, S, self.config.hidden_size)
+        return self.hidden_states(x, packed=False).float().view(B, S, self.config.hidden_size)

@@ -109,8 +109,13 @@ class MMGCLIP(nn.Module):
 
     def encode_text(self, batch, text_pooling='eos'):
         """BERT last hidden state pooled at the [SEP] position = attention_mask.sum(-1) - 1 (mmgclip_model.py:95-115)."""
-        tokens = batch['text_tokens'].to(self.device) if hasattr(batch['text_tokens'], "to") else \
-            {k: v.to(self.device) for k, v in batch['text_tokens'].items()}
+        src = batch['text_tokens']
+        host_mask = src['attention_mask'] if ('attention_mask' in src and not src['attention_mask'].is_cuda) else None
+        tokens = src.to(self.device) if hasattr(src, "to") else {k: v.to(self.device) for k, v in src.items()}
+        if host_mask is not None and tokens['attention_mask'] is not host_mask:
+            # prompt lengths read from the batch while it is still on the host: the unpadded text tower needs them there
+            m = tokens['attention_mask']
+            m._mmg_seq_lens = (m._version, type(self.text_encoder).sequence_lengths(host_mask))
         if isinstance(batch, dict):
             batch['text_tokens'] = tokens                      # the reference's BatchEncoding.to() is in-place
         hidden = self.text_encoder.hidden_states(tokens)       # bf16 [n*S, H]

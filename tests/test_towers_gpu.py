@@ -272,3 +272,33 @@ def test_bert_encoder_loads_huggingface_directory(dev, tmp_path):
     valid = mask.bool()
     r, c = _rel(got[valid], want[valid])
     assert r < 3e-2 and c > 0.999, (r, c)
+
+
+def test_bert_packed_layout_equals_padded(dev):
+    """The unpadded path (valid tokens only, mmg_attention_varlen_*) gives the padded path's hidden states on every valid row
+    and the same parameter gradients; its padding rows are zeros."""
+    from mmgclip.networks.bert import BertConfigLite
+    from mmgclip.networks.encoder import BertEncoder
+    from mmgclip.dataset.synthetic import synthetic_tokens
+    torch.manual_seed(0)
+    cfg = BertConfigLite(vocab_size=3000, num_hidden_layers=2)
+    enc = BertEncoder(pretrained=None, random_init=True, freeze=False, config=cfg).to(dev)
+    _randomize(enc, 4)
+    tok = {k: v.to(dev) for k, v in synthetic_tokens(6, 77, 3000, torch.Generator().manual_seed(5)).items()}
+    valid = tok["attention_mask"].reshape(-1, 1).bool()
+    wgt = torch.randn(6 * 77, 768, generator=torch.Generator().manual_seed(6)).to(dev)
+    outs, grads = [], []
+    for packed in (False, True):
+        enc.zero_grad(set_to_none=True)
+        h = enc.hidden_states(tok, packed=packed)
+        (h.float() * wgt * valid).sum().backward()
+        outs.append(h.float())
+        grads.append({n: p.grad.clone() for n, p in enc.model.named_parameters() if p.grad is not None})
+    assert float(outs[1][~valid.expand_as(outs[1])].abs().max()) == 0.0
+    r, c = _rel(outs[1] * valid, outs[0] * valid)
+    assert r < 1e-2 and c > 0.9999, (r, c)
+    for n, g0 in grads[0].items():
+        if n.endswith("attention.self.key.bias") or n.startswith("pooler."):
+            continue
+        r, c = _rel(grads[1][n], g0)
+        assert c > 0.999 and r < 3e-2, (n, r, c)
