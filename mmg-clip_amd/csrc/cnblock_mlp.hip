@@ -1,4 +1,4 @@
-// Fused ConvNeXt block MLP for the narrow stages (C <= 256):   y = x + gamma * ( GELU( LN(d) W1^T + b1 ) W2^T + b2 )
+// Fused ConvNeXt block MLP for the narrow stages (C <= 384):   y = x + gamma * ( GELU( LN(d) W1^T + b1 ) W2^T + b2 )
 //
 // Replaces, for torchvision's CNBlock (reference: mmgclip/networks/encoder.py:53 runs `model.features`; module tree in
 // notebooks/clf_convnext_tiny_experimental.ipynb cell 3: LayerNorm -> Linear(C,4C) -> GELU -> Linear(4C,C) -> layer_scale
@@ -6,7 +6,7 @@
 // (17C bytes/pixel of traffic in the forward).  Here the 4C hidden row never leaves the CU: HBM traffic is d (C) in, x (C)
 // in, y (C) out.
 //
-// Structure (one workgroup = 4 waves = 128 rows, each wave owns 32 rows end to end):
+// Structure (one workgroup = 4 waves x 32 rows; 8 waves x 16 rows at C = 384 - MlpCfg; each wave owns its rows end to end):
 //   * the wave loads its rows of d straight into MFMA B-operand fragments (lane = row, 8 consecutive k), LayerNorm is done
 //     in registers (row statistics need two xor-shuffles: the 4 lanes {l, l^16, l^32, l^48} share a row);
 //   * the two weight matrices are pre-packed on the device (mmg_cnblock_pack_weights) into per-chunk LDS images, so a
@@ -14,9 +14,11 @@
 //     buffered, one barrier per chunk; fragment reads are conflict-free ds_read_b128 by construction (16 consecutive
 //     granules per 16-lane group);
 //   * both MFMAs are issued swapped (A := weight fragment), so the accumulator of GEMM 1 leaves lane l with row l&15 and 4
-//     consecutive hidden columns: bias + GELU are applied in place and two such tiles ARE the B operand of GEMM 2's
-//     16x16x32 step (the k-order this implies is folded into the packing of W2) - no LDS round trip for the hidden row.
-// The bound is the fp32 VALU (erf-GELU, ~18 ops per hidden element = 3x the MFMA time at C=96), then HBM.
+//     consecutive row positions of the weight tile: bias + GELU are applied in place and two such tiles ARE the B operand
+//     of GEMM 2's 16x16x32 step - no LDS round trip for the hidden row.  The packing places the hidden units (and the output
+//     columns) so that a lane's pair of tiles is 8 consecutive units: every global access of the kernels is 16 bytes.
+// The bound is the fp32 VALU (erf-GELU, ~15 instructions per hidden element = 3x the MFMA time at C=96), then HBM; the
+// backward (cnblock_mlp_bwd_kernel below) recomputes the hidden row and is bound by its 4C-wide stores.
 #include "common.h"
 #include <stdlib.h>
 

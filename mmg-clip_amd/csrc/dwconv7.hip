@@ -5,7 +5,7 @@
 // mmgclip/networks/image_features.py:100; module tree in notebooks/clf_convnext_tiny_experimental.ipynb cell 3).
 //
 // Not a GEMM: 49 MAC per output and no channel reduction, so it runs on the fp32 VALU with the tile in LDS.
-// A workgroup owns a 16x32 pixel tile of a 32-channel slab: the (16+6)x(32+6) halo tile is staged once
+// A workgroup owns an 8x32 pixel tile of a 32-channel slab: the (8+6)x(32+6) halo tile is staged once
 // (16-byte coalesced loads, zero padded), a lane owns a channel pair and a strip of 8 output pixels along W and
 // slides the 7-tap window over a row of 14 inputs held in registers (56 packed FMAs per 14 LDS reads).
 // The same kernel with the taps flipped is the data gradient; the weight gradient keeps the 49 taps of its channel

@@ -13,8 +13,10 @@ state dict loads unchanged.  Stochastic depth is not applied (p = 0).
 
 Data layout on the MI355X: activations are bf16 [n*H*W, C] (NHWC flattened), so every pointwise Linear is a plain
 row-major GEMM and LayerNorm reads contiguous rows; the 2x2/4x4 stride=kernel convolutions become GEMMs on patchified
-rows (the LayerNorm kernel writes the patchified layout directly).  Saved for backward per block and pixel: block input
-(C), depthwise output (C), pre-GELU hidden (4C) in bf16 + LN statistics; LN output and GELU output are rebuilt.
+rows (the LayerNorm kernel writes the patchified layout directly).  Blocks with C <= 384 run LayerNorm + Linear + GELU +
+Linear + layer scale + residual as one fused launch (csrc/cnblock_mlp.hip); for C <= 192 the backward recomputes the hidden
+row on chip.  Saved for backward per block and pixel: block input (C), depthwise output (C) and - only where the backward
+does not recompute it - the pre-GELU hidden (4C) in bf16 + LN statistics; LN output and GELU output are rebuilt.
 """
 import os
 
