@@ -412,11 +412,43 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         out[idx] = f2bf(v);
     }
 }
+// Cin = 1, P = 4 (the mammography stem): one thread per output row - four 16-byte loads (one per kernel row, consecutive lanes
+// = consecutive patches of an image row), 32 bytes of bf16 out + zero padding, all as 16-byte stores.
+__global__ __launch_bounds__(256) void patchify_1x4_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int H, int W,
+                                                           int Kp, int scale16, size_t rows) {
+    const int Ho = H / 4, Wo = W / 4;
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < rows; row += (size_t)gridDim.x * 256) {
+        const int wo = (int)(row % Wo), ho = (int)((row / Wo) % Ho);
+        const size_t n = row / ((size_t)Wo * Ho);
+        const float* src = img + (n * H + (size_t)ho * 4) * W + wo * 4;
+        unsigned pk[8];
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            float4 v = *reinterpret_cast<const float4*>(src + (size_t)kh * W);
+            if (scale16) {
+                v.x = (v.x * 65535.0f - 32767.5f) / 32767.5f; v.y = (v.y * 65535.0f - 32767.5f) / 32767.5f;
+                v.z = (v.z * 65535.0f - 32767.5f) / 32767.5f; v.w = (v.w * 65535.0f - 32767.5f) / 32767.5f;
+            }
+            pk[2 * kh] = pack2bf(v.x, v.y); pk[2 * kh + 1] = pack2bf(v.z, v.w);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(out + row * Kp);
+        dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        for (int z = 2; z < Kp / 8; ++z) dst[z] = make_uint4(0, 0, 0, 0);
+    }
+}
+
 MMG_API int mmg_patchify(const float* img, void* out, int n, int Cin, int H, int W, int P, int Kp, int scale16,
                          hipStream_t stream) {
     MMG_CHECK_ARG(img && out && n > 0 && Cin > 0 && P > 0 && H >= P && W >= P && Kp >= P * P * Cin && Kp % 8 == 0,
                   "mmg_patchify: bad argument (H=%d W=%d P=%d Cin=%d Kp=%d)", H, W, P, Cin, Kp);
     const size_t rows = (size_t)n * (H / P) * (W / P);
+    if (Cin == 1 && P == 4 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0) {
+        const int blocks = (int)((rows + 255) / 256 > 16384 ? 16384 : (rows + 255) / 256);
+        hipLaunchKernelGGL(patchify_1x4_kernel, dim3(blocks), dim3(256), 0, stream, img, (bf16_t*)out, H, W, Kp, scale16, rows);
+        MMG_LAUNCH_CHECK("mmg_patchify");
+        return 0;
+    }
     size_t total = rows * Kp;
     int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, stream, img, (bf16_t*)out, Cin, H, W, P, Kp, scale16, rows);

@@ -78,14 +78,15 @@ def test_avgpool(dev):
     _close(dx, (dy / HW)[:, None, :].expand(n, HW, C).reshape(n * HW, C), 1e-2, 1e-6)
 
 
-def test_patchify_matches_conv_unfold(dev):
+@pytest.mark.parametrize("cin,kp", [(1, 32), (3, 64)])       # 1 channel: the 16-byte fast path; 3 channels: the generic kernel
+def test_patchify_matches_conv_unfold(dev, cin, kp):
     from mmgclip import kernels as K
-    img = torch.rand(2, 1, 32, 48, generator=torch.Generator().manual_seed(14)).to(dev)
-    p = K.patchify(img, 4, 32, True)
+    img = torch.rand(2, cin, 32, 48, generator=torch.Generator().manual_seed(14)).to(dev)
+    p = K.patchify(img, 4, kp, True)
     scaled = (img * 65535.0 - 32767.5) / 32767.5
-    ref = scaled.reshape(2, 1, 8, 4, 12, 4).permute(0, 2, 4, 3, 5, 1).reshape(2 * 8 * 12, 16)
-    _close(p[:, :16], ref, 1e-2, 1e-2)
-    assert (p[:, 16:] == 0).all()
+    ref = scaled.reshape(2, cin, 8, 4, 12, 4).permute(0, 2, 4, 3, 5, 1).reshape(2 * 8 * 12, 16 * cin)
+    _close(p[:, :16 * cin], ref, 1e-2, 1e-2)
+    assert (p[:, 16 * cin:] == 0).all()
 
 
 def test_adamw_matches_torch(dev):
