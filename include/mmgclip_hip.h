@@ -206,6 +206,35 @@ int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const
                         void* dxln, float* mean, float* rstd, float* ln_dw, float* ln_db, long long M, int C,
                         mmg_stream_t stream);
 
+/* ---- ResNet-50 tower pieces (reference ResNet50Encoder, mmgclip/networks/encoder.py:57-119: torchvision resnet50 minus fc,
+ * everything frozen except layer4).  NHWC bf16; convolutions = im2col + mmg_gemm_nt_bf16 (1x1: no im2col at all). ------------ */
+
+/* col[n*Ho*Wo, Kp] (bf16) from x[n,H,W,C]: column (kh*KW + kw)*C + c, zeros outside the image and in the K padding; C % 8 == 0. */
+int mmg_im2col_nhwc(const void* x, void* col, int n, int H, int W, int C, int KH, int KW, int stride, int pad, int Kp,
+                    mmg_stream_t stream);
+/* dx[n,H,W,C] = adjoint of mmg_im2col_nhwc applied to dcol (data gradient of a k x k convolution); gather, no atomics. */
+int mmg_col2im_nhwc(const void* dcol, void* dx, int n, int H, int W, int C, int KH, int KW, int stride, int pad, int Kp,
+                    mmg_stream_t stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) forward (encoder.py:107). */
+int mmg_maxpool3x3s2_nhwc(const void* x, void* y, int n, int H, int W, int C, mmg_stream_t stream);
+/* nn.BatchNorm2d on rows [M = n*H*W, C]: column sums of x and x^2 (fp32, accumulated; zero them first) ... */
+int mmg_bn_stats(const void* x, int M, int C, float* sum, float* sumsq, mmg_stream_t stream);
+/* ... -> mean / rstd and the fused affine (scale, shift).  train != 0: batch statistics (biased variance) and torch's
+ * running-statistics update with `momentum` (unbiased variance); train == 0: the running statistics are used. */
+int mmg_bn_finalize(const float* sum, const float* sumsq, int M, int C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, int train, float* mean, float* rstd,
+                    float* scale, float* shift, mmg_stream_t stream);
+/* y = x * scale[c] + shift[c] (+ residual) (ReLU when relu != 0): bn + the bottleneck's shortcut add + ReLU in one pass. */
+int mmg_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, void* y, int M, int C, int relu,
+                 mmg_stream_t stream);
+/* Training-mode backward of y = relu?(bn(x) (+ residual)): g = dy masked by `out` > 0 (the layer's own output; NULL = no ReLU).
+ * reduce: sum_g[c] += g, sum_gx[c] += g * xhat (= d beta, d gamma).  apply: dx = gamma rstd (g - sum_g/M - xhat sum_gx/M);
+ * dres (nullable) = g, the gradient of the residual branch. */
+int mmg_bn_bwd_reduce(const void* dy, const void* x, const void* out, const float* mean, const float* rstd, int M, int C,
+                      float* sum_g, float* sum_gx, mmg_stream_t stream);
+int mmg_bn_bwd_apply(const void* dy, const void* x, const void* out, const float* mean, const float* rstd, const float* gamma,
+                     const float* sum_g, const float* sum_gx, int M, int C, void* dx, void* dres, mmg_stream_t stream);
+
 /* ---- BERT attention / embeddings / pooling -------------------------------------------------------------------- */
 
 /* ctx[B*S,Hd] = per-head softmax(Q K^T * scale + key mask) V with qkv = [B*S, q|k|v] bf16 (head h at columns h*64

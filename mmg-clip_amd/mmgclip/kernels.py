@@ -212,3 +212,59 @@ def eos_pool_bwd(dout, idx, B, S):
     dh = torch.empty(B * S, H, device=dout.device, dtype=BF16)
     call("mmg_eos_pool_bwd", ptr(dout), ptr(idx), ptr(dh), B, S, H, stream())
     return dh
+
+
+# ---- ResNet-50 tower pieces (csrc/resnet_ops.hip) -----------------------------------------------------------------------
+def conv_out_hw(H, W, k, stride, pad):
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def im2col(x, n, H, W, C, k, stride, pad, Kp):
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad)
+    col = torch.empty(n * Ho * Wo, Kp, device=x.device, dtype=BF16)
+    call("mmg_im2col_nhwc", ptr(x), ptr(col), n, H, W, C, k, k, stride, pad, Kp, stream())
+    return col
+
+
+def col2im(dcol, n, H, W, C, k, stride, pad):
+    dx = torch.empty(n * H * W, C, device=dcol.device, dtype=BF16)
+    call("mmg_col2im_nhwc", ptr(dcol), ptr(dx), n, H, W, C, k, k, stride, pad, dcol.shape[1], stream())
+    return dx
+
+
+def maxpool3x3s2(x, n, H, W, C):
+    Ho, Wo = conv_out_hw(H, W, 3, 2, 1)
+    y = torch.empty(n * Ho * Wo, C, device=x.device, dtype=BF16)
+    call("mmg_maxpool3x3s2_nhwc", ptr(x), ptr(y), n, H, W, C, stream())
+    return y
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, train, eps=1e-5, momentum=0.1, residual=None, relu=False):
+    """nn.BatchNorm2d on rows [M, C] (+ shortcut add + ReLU in the same pass) -> y, mean, rstd."""
+    M, C = x.shape
+    dev = x.device
+    st = torch.zeros(2, C, device=dev, dtype=torch.float32) if train else None
+    if train:
+        call("mmg_bn_stats", ptr(x), M, C, ptr(st[0]), ptr(st[1]), stream())
+    out4 = torch.empty(4, C, device=dev, dtype=torch.float32)          # mean, rstd, scale, shift
+    call("mmg_bn_finalize", ptr(st[0]) if train else None, ptr(st[1]) if train else None, M, C, ptr(gamma), ptr(beta), float(eps),
+         float(momentum), ptr(running_mean), ptr(running_var), 1 if train else 0, ptr(out4[0]), ptr(out4[1]), ptr(out4[2]),
+         ptr(out4[3]), stream())
+    y = torch.empty_like(x)
+    call("mmg_bn_apply", ptr(x), ptr(out4[2]), ptr(out4[3]), ptr(residual), ptr(y), M, C, 1 if relu else 0, stream())
+    return y, out4[0], out4[1]
+
+
+def batchnorm_bwd(dy, x, out, mean, rstd, gamma, dgamma, dbeta, want_dres=False):
+    """Training-mode backward of y = relu?(bn(x) (+ res)); `out` = the layer's own output (ReLU mask) or None.
+    Accumulates dgamma / dbeta; returns dx (and the masked gradient of the residual branch when want_dres)."""
+    M, C = x.shape
+    sums = torch.zeros(2, C, device=x.device, dtype=torch.float32)
+    call("mmg_bn_bwd_reduce", ptr(dy), ptr(x), ptr(out), ptr(mean), ptr(rstd), M, C, ptr(sums[0]), ptr(sums[1]), stream())
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    call("mmg_bn_bwd_apply", ptr(dy), ptr(x), ptr(out), ptr(mean), ptr(rstd), ptr(gamma), ptr(sums[0]), ptr(sums[1]), M, C,
+         ptr(dx), ptr(dres), stream())
+    dbeta.add_(sums[0])
+    dgamma.add_(sums[1])
+    return dx, dres

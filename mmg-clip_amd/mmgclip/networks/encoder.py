@@ -18,6 +18,7 @@ import torch.nn as nn
 from ..utils.logger import logger
 from .bert import BertConfigLite, BertTower
 from .convnext import ConvNextTower
+from .resnet import ResNetTower
 from .vit import ViTTower
 
 PROJECTION_HEAD_DIM = 512
@@ -57,12 +58,23 @@ class ConvNextTiny(nn.Module):
         return self._tower(x).reshape(x.shape[0], -1, 1, 1)
 
 
-class ResNet50Encoder(nn.Module):
+class ResNet50Encoder(ResNetTower):
+    """`ResNet50Encoder(pretrained=True, image_features_dimension=768)`; attrs `model`, `model_output_dimension` = 2048; everything
+    frozen except `layer4` (mmgclip/networks/encoder.py:57-89).  `pretrained` may be a path to a torchvision resnet50 state dict
+    (.pth / .safetensors); the hub download of the reference (`models.resnet50(pretrained=True)`) is impossible offline, so
+    `pretrained=True` without MMGCLIP_RESNET50_WEIGHTS set means torchvision's random initialisation (logged)."""
+
     def __init__(self, pretrained=True, image_features_dimension=768):
         super().__init__()
-        raise NotImplementedError(
-            "ResNet50Encoder (torchvision ResNet-50, reference mmgclip/networks/encoder.py:57-119) is outside the "
-            "MI355X hot path built so far (SURVEY.md §8 a4/f4); use ConvNextTiny features or ConvNextTinyEncoder.")
+        logger.info("Initializing 'resnet50' as the image encoder.")
+        path = pretrained if isinstance(pretrained, str) else os.environ.get("MMGCLIP_RESNET50_WEIGHTS")
+        if path:
+            assert os.path.isfile(path), f"ResNet-50 weights not found: {path}"
+            sd = _load_state_file(path)
+            sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+            self.model.load_state_dict(sd, strict=True)
+        elif pretrained:
+            logger.info("no local ResNet-50 weights (MMGCLIP_RESNET50_WEIGHTS): random initialisation")
 
 
 class _ConvNextEncoder(ConvNextTower):

@@ -109,3 +109,39 @@ def vit_forward(sd, images, heads=12, patch=16, scale16=True, prefix=""):
         i += 1
     x = F.layer_norm(x, (H,), g("encoder.ln.weight"), g("encoder.ln.bias"), 1e-6)
     return x[:, 0]
+
+
+def resnet50_forward(sd, images, train_bn=True, prefix="", storage_bf16=False):
+    """torchvision resnet50 without `fc`, as the reference's ResNet50Encoder.forward runs it (mmgclip/networks/encoder.py:
+    101-117), from a state dict (fp32).  train_bn=True: batch statistics in every BatchNorm (the reference calls model.train()
+    on the whole model; frozen layers included).  storage_bf16=True rounds every stored activation and every weight to bf16 (fp32
+    arithmetic in between), i.e. the storage format of the device path: 53 batch-statistics normalisations in a row amplify
+    that rounding, so the tight comparison of the device tower is against this variant.  Returns [n, 2048]."""
+    q = (lambda t: t.to(torch.bfloat16).float()) if storage_bf16 else (lambda t: t)          # noqa: E731
+    g = lambda k: sd[prefix + k]                                           # noqa: E731
+    conv = lambda x, k, **kw: q(F.conv2d(x, q(g(k)), **kw))                # noqa: E731
+
+    def bn(x, k, res=None, relu=True):
+        if train_bn:
+            y = F.batch_norm(x, None, None, g(k + ".weight"), g(k + ".bias"), True, 0.1, 1e-5)
+        else:
+            y = F.batch_norm(x, g(k + ".running_mean"), g(k + ".running_var"), g(k + ".weight"), g(k + ".bias"), False, 0.1, 1e-5)
+        if res is not None:
+            y = y + res
+        return q(F.relu(y) if relu else y)
+
+    x = images
+    if x.dim() == 2:
+        x = x.view(x.shape[0], 1, 1, x.shape[1]).repeat(1, 3, 1, 1)
+    x = bn(conv(q(x), "conv1.weight", stride=2, padding=3), "bn1")
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, (blocks, stride) in enumerate(((3, 1), (4, 2), (6, 2), (3, 2))):
+        for bi in range(blocks):
+            k = f"layer{li + 1}.{bi}."
+            s = stride if bi == 0 else 1
+            y = bn(conv(x, k + "conv1.weight"), k + "bn1")
+            y = bn(conv(y, k + "conv2.weight", stride=s, padding=1), k + "bn2")
+            y = conv(y, k + "conv3.weight")
+            idn = bn(conv(x, k + "downsample.0.weight", stride=s), k + "downsample.1", relu=False) if bi == 0 else x
+            x = bn(y, k + "bn3", res=idn)
+    return F.adaptive_avg_pool2d(x, 1).flatten(1)

@@ -120,3 +120,37 @@ def test_mmgclip_and_averaged_losses(dev, golden_dir):
     assert abs(loss.item() - float(a["loss"])) < 1e-5 * abs(float(a["loss"]))
     with pytest.raises(ValueError):
         create_loss("NoSuchLoss")
+
+
+def test_resnet50_image_encoder_config(dev, monkeypatch):
+    """networks=clip_resnet50_bert (reference configs/networks/clip_resnet50_bert.yaml): the precomputed [n,768] feature vector
+    goes through ResNet50Encoder as a 1 x 768 three-channel image (encoder.py:101-103), layer4 and the two heads train."""
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    from mmgclip.optim import FusedAdamW
+    _small_bert(monkeypatch)
+    torch.manual_seed(0)
+    cfg = _cfg("networks=clip_resnet50_bert", "networks.text_encoder.random_init=true", "tokenizer=bert_clinical_seqlen=77")
+    model = MMGCLIP(cfg)
+    model.train()
+    trainable = {n.split(".")[0] + "." + n.split(".")[2] if n.startswith("image_encoder") else n for n, p in model.named_parameters()
+                 if p.requires_grad}
+    assert trainable == {"image_encoder.layer4", "image_projection_layer.layer.weight", "text_projection_layer.layer.weight"}
+    assert model.image_projection_layer.layer.weight.shape == (512, 2048)
+    batch = synthetic_batch(16, S=77, vocab_size=3000, seed=4)
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-4,
+                     arenas=[model.image_encoder.arena] if model.image_encoder.arena is not None else [])
+    crit = create_loss("CLIPLoss")()
+    losses = []
+    w_frozen = model.image_encoder.model.layer1[0].conv1.weight.detach().clone()
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = crit(**model(batch))
+        loss.backward()
+        if not opt.arenas and model.image_encoder.arena is not None:
+            opt.arenas.append(model.image_encoder.arena)
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert torch.equal(w_frozen, model.image_encoder.model.layer1[0].conv1.weight.detach())
