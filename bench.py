@@ -227,7 +227,8 @@ def main():
                    "algorithmic_gflop_per_pair": gflop,
                    "model_tflops_per_gpu": round(value * gflop / 1000.0 / world, 1) if gflop else None,
                    "mfma_utilisation_model_flops": round(value * gflop / 1000.0 / world / MFMA_BF16_PEAK_TFLOPS, 4) if gflop else None,
-                   "final_loss": round(losses[-1], 5)},
+                   "final_loss": round(losses[-1], 5),
+                   "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
     }
     if rank == 0:
         if not args.no_roofline:
