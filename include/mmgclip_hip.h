@@ -229,11 +229,12 @@ int mmg_bn_apply(const void* x, const float* scale, const float* shift, const vo
                  mmg_stream_t stream);
 /* Training-mode backward of y = relu?(bn(x) (+ residual)): g = dy masked by `out` > 0 (the layer's own output; NULL = no ReLU).
  * reduce: sum_g[c] += g, sum_gx[c] += g * xhat (= d beta, d gamma).  apply: dx = gamma rstd (g - sum_g/M - xhat sum_gx/M);
- * dres (nullable) = g, the gradient of the residual branch. */
+ * dres (nullable) = g, the gradient of the residual branch; dgamma / dbeta (nullable pair, fp32 [C]) += sum_gx / sum_g. */
 int mmg_bn_bwd_reduce(const void* dy, const void* x, const void* out, const float* mean, const float* rstd, int M, int C,
                       float* sum_g, float* sum_gx, mmg_stream_t stream);
 int mmg_bn_bwd_apply(const void* dy, const void* x, const void* out, const float* mean, const float* rstd, const float* gamma,
-                     const float* sum_g, const float* sum_gx, int M, int C, void* dx, void* dres, mmg_stream_t stream);
+                     const float* sum_g, const float* sum_gx, int M, int C, void* dx, void* dres, float* dgamma, float* dbeta,
+                     mmg_stream_t stream);
 
 /* ---- BERT attention / embeddings / pooling -------------------------------------------------------------------- */
 

@@ -263,9 +263,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ out, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ sum_g, const float* __restrict__ sum_gx, int M,
-                                                           int C, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, size_t nvec) {
+                                                           int C, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, size_t nvec,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int cvec = C / 8;
     const float inv = 1.0f / M;
+    if (blockIdx.x == 0 && dgamma) {                   // parameter gradients (accumulated): d gamma = sum g xhat, d beta = sum g
+        for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += sum_gx[c]; dbeta[c] += sum_g[c]; }
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % cvec) * 8;
         const uint4 gv = *reinterpret_cast<const uint4*>(dy + i * 8), xv = *reinterpret_cast<const uint4*>(x + i * 8);
@@ -300,12 +304,14 @@ MMG_API int mmg_bn_bwd_reduce(const void* dy, const void* x, const void* out, co
 }
 
 MMG_API int mmg_bn_bwd_apply(const void* dy, const void* x, const void* out, const float* mean, const float* rstd, const float* gamma,
-                             const float* sum_g, const float* sum_gx, int M, int C, void* dx, void* dres, hipStream_t stream) {
+                             const float* sum_g, const float* sum_gx, int M, int C, void* dx, void* dres, float* dgamma,
+                             float* dbeta, hipStream_t stream) {
     MMG_CHECK_ARG(dy && x && mean && rstd && gamma && sum_g && sum_gx && dx && M > 0 && C >= 8 && C % 8 == 0, "mmg_bn_bwd_apply: bad argument");
+    MMG_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "mmg_bn_bwd_apply: dgamma and dbeta go together");
     const size_t nvec = (size_t)M * C / 8;
     const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)out, mean,
-                       rstd, gamma, sum_g, sum_gx, M, C, (bf16_t*)dx, (bf16_t*)dres, nvec);
+                       rstd, gamma, sum_g, sum_gx, M, C, (bf16_t*)dx, (bf16_t*)dres, nvec, dgamma, dbeta);
     MMG_LAUNCH_CHECK("mmg_bn_bwd_apply");
     return 0;
 }

@@ -264,7 +264,5 @@ def batchnorm_bwd(dy, x, out, mean, rstd, gamma, dgamma, dbeta, want_dres=False)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     call("mmg_bn_bwd_apply", ptr(dy), ptr(x), ptr(out), ptr(mean), ptr(rstd), ptr(gamma), ptr(sums[0]), ptr(sums[1]), M, C,
-         ptr(dx), ptr(dres), stream())
-    dbeta.add_(sums[0])
-    dgamma.add_(sums[1])
+         ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream())
     return dx, dres
