@@ -39,3 +39,40 @@ def test_convnext_geometry_matches_notebook():
     assert fmap.shape == (1, 768, x.shape[2] // 32, 4) and pooled.shape == (1, 768, 1, 1)
     assert (1906 // 32, 818 // 32) == (59, 25)
     assert sum(p.numel() for p in feats.parameters()) == 27_815_520   # ConvNeXt-T trunk with a 1-channel stem
+
+
+def test_resnet50_oracle_equals_the_torch_modules_of_the_same_tree():
+    """oracle.resnet50_forward (functional, from a state dict) vs the nn.Conv2d / nn.BatchNorm2d modules of the torchvision-layout
+    tree run directly in torch - train mode (batch statistics) and eval mode (running statistics), 4-D and the reference's 2-D
+    input (mmgclip/networks/encoder.py:101-117)."""
+    import torch.nn.functional as F
+    from mmgclip.networks.resnet import _TorchvisionResNet
+    torch.manual_seed(0)
+    m = _TorchvisionResNet()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n_, b in m.named_buffers():
+            if n_.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            elif n_.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+
+    def run(x):
+        if x.dim() == 2:
+            x = x.view(x.shape[0], 1, 1, x.shape[1]).repeat(1, 3, 1, 1)
+        x = F.max_pool2d(F.relu(m.bn1(m.conv1(x))), 3, 2, 1)
+        for li in range(4):
+            for blk in getattr(m, f"layer{li + 1}"):
+                y = F.relu(blk.bn1(blk.conv1(x)))
+                y = F.relu(blk.bn2(blk.conv2(y)))
+                y = blk.bn3(blk.conv3(y))
+                x = F.relu(y + (blk.downsample(x) if blk.downsample is not None else x))
+        return F.adaptive_avg_pool2d(x, 1).flatten(1)
+
+    for x in (torch.rand(2, 3, 64, 64, generator=g), torch.rand(3, 96, generator=g)):
+        sd = {k: v.clone() for k, v in m.state_dict().items()}      # (a train-mode run of the modules moves their running statistics)
+        with torch.no_grad():
+            m.eval()
+            assert torch.allclose(E.resnet50_forward(sd, x, train_bn=False), run(x), rtol=1e-4, atol=1e-5)
+            m.train()
+            assert torch.allclose(E.resnet50_forward(sd, x, train_bn=True), run(x), rtol=1e-3, atol=1e-4)
