@@ -49,6 +49,7 @@ def test_registries_raise_like_the_reference():
     assert create_loss("CLIPLoss").__name__ == "CLIPLoss"
     assert get_projection_head("MultiLinearHead").__name__ == "MultiLinearHead"
     assert getNetworkClass("BertEncoder").__name__ == "BertEncoder"
+    assert getNetworkClass("ResNet50Encoder").__name__ == "ResNet50Encoder"
     assert create_experiment("classification").__name__ == "ClassifierExperiment"
     for fn, bad in ((create_loss, "X"), (get_projection_head, "ZeroProjection"), (getNetworkClass, "ConvNextTiny"), (create_experiment, "x")):
         with pytest.raises(ValueError, match="Invalid network_name"):
@@ -69,6 +70,8 @@ def test_config_composer_reproduces_the_reference_surface():
     r = compose(cfg_dir, "train_exam_reports_clf", ["loss=mmgclip", "optimizer.config.learning_rate=1e-3"])
     assert r.projection.config.output_projection_dimension == [768, 512] and r.loss.config.loss_name == "MMGCLIPLoss"
     assert r.base.features_export_dir == "outputs/dataset/reports_studies/4_avg" and r.optimizer.config.learning_rate == 1e-3
+    rn = compose(cfg_dir, "train_binary_class_clf", ["networks=clip_resnet50_bert"])        # reference configs/networks/clip_resnet50_bert.yaml
+    assert rn.networks.image_encoder.name == "ResNet50Encoder" and rn.networks.image_encoder.image_features_dimension == 2048
 
 
 def test_product_path_fails_loudly_without_gpu():
