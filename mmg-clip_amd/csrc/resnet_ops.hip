@@ -129,19 +129,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
                                                        float* __restrict__ sum, float* __restrict__ sumsq) {
     const int cvec = C / 8;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
-    for (int cv = threadIdx.x % cvec; cv < cvec; cv += cvec) {          // one column group per thread (cvec <= 256)
-        const int lanes = 256 / cvec, sub = threadIdx.x / cvec;
-        if (sub >= lanes) break;
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int r = r0 + sub; r < r1; r += lanes) {
-            const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)r * C + cv * 8);
-            const float f[8] = {bf2f_lo(v.x), bf2f_hi(v.x), bf2f_lo(v.y), bf2f_hi(v.y), bf2f_lo(v.z), bf2f_hi(v.z), bf2f_lo(v.w), bf2f_hi(v.w)};
+    // thread = (column group cv of 8 channels, row phase sub); 256 / cvec threads share a column group (cvec <= 256)
+    const int cv = threadIdx.x % cvec, lanes = 256 / cvec, sub = threadIdx.x / cvec;
+    if (sub >= lanes) return;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + sub; r < r1; r += lanes) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)r * C + cv * 8);
+        const float f[8] = {bf2f_lo(v.x), bf2f_hi(v.x), bf2f_lo(v.y), bf2f_hi(v.y), bf2f_lo(v.z), bf2f_hi(v.z), bf2f_lo(v.w), bf2f_hi(v.w)};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(sum + cv * 8 + e, s[e]); atomicAdd(sumsq + cv * 8 + e, q[e]); }
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(sum + cv * 8 + e, s[e]); atomicAdd(sumsq + cv * 8 + e, q[e]); }
 }
 
 MMG_API int mmg_bn_stats(const void* x, int M, int C, float* sum, float* sumsq, hipStream_t stream) {
