@@ -176,7 +176,7 @@ int mmg_dwconv7_nhwc_mfma(const void* x, const float* w, const float* bias, cons
 int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int H, int W, int C,
                       mmg_stream_t stream);
 
-/* ---- fused ConvNeXt block MLP (C in {96,128,192,256,384}) ---------------------------------------------------------- */
+/* ---- fused ConvNeXt block MLP (C in {96,128,192,256,384,512}) ---------------------------------------------------------- */
 
 /* Number of bf16 elements of the packed weight image (8C^2 forward / backward=2, 12C^2 backward=1); 0 when C is unsupported. */
 long long mmg_cnblock_packed_elems(int C, int backward);

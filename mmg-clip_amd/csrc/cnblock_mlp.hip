@@ -579,7 +579,7 @@ static int launch_mlp_fwd(MlpFwd p, hipStream_t stream) {
     return 0;
 }
 
-static bool mlp_supported(int C) { return C == 96 || C == 128 || C == 192 || C == 256 || C == 384; }
+static bool mlp_supported(int C) { return C == 96 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512; }
 
 MMG_API long long mmg_cnblock_packed_elems(int C, int backward) {
     if (!mlp_supported(C)) return 0;
@@ -589,7 +589,7 @@ MMG_API long long mmg_cnblock_packed_elems(int C, int backward) {
 MMG_API int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamma, void* packed, int C, int backward,
                                      hipStream_t stream) {
     MMG_CHECK_ARG(w1 && w2 && packed, "mmg_cnblock_pack_weights: null pointer");
-    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_pack_weights: C=%d not in {96,128,192,256,384}", C);
+    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_pack_weights: C=%d not in {96,128,192,256,384,512}", C);
     MMG_CHECK_ARG(backward >= 0 && backward <= 2, "mmg_cnblock_pack_weights: backward=%d not in {0,1,2}", backward);
     MMG_CHECK_ARG(!backward || gamma, "mmg_cnblock_pack_weights: the backward image needs the layer scale");
     PackArgs a{};
@@ -616,7 +616,7 @@ MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* 
                                 const float* b1, const float* b2, const float* gamma, const void* residual, void* y,
                                 void* hpre, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
     MMG_CHECK_ARG(xd && ln_w && ln_b && packed && b1 && b2 && gamma && residual && y, "mmg_cnblock_mlp_fwd: null pointer");
-    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_mlp_fwd: C=%d not in {96,128,192,256,384}", C);
+    MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_mlp_fwd: C=%d not in {96,128,192,256,384,512}", C);
     MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_fwd: bad M=%lld", M);
     MMG_CHECK_ARG((mean == nullptr) == (hpre == nullptr) && (rstd == nullptr) == (hpre == nullptr),
                   "mmg_cnblock_mlp_fwd: hpre, mean and rstd are saved together or not at all");
@@ -627,7 +627,8 @@ MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* 
         case 128: return launch_mlp_fwd<128>(p, stream);
         case 192: return launch_mlp_fwd<192>(p, stream);
         case 256: return launch_mlp_fwd<256>(p, stream);
-        default: return launch_mlp_fwd<384>(p, stream);
+        case 384: return launch_mlp_fwd<384>(p, stream);
+        default: return launch_mlp_fwd<512>(p, stream);
     }
 }
 

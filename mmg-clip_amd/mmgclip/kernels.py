@@ -102,7 +102,7 @@ def dwconv7_wgrad(x, dy, dw49, dbias, n, H, W, C):
 
 
 def cnblock_supported(C):
-    return C in (96, 128, 192, 256, 384)
+    return C in (96, 128, 192, 256, 384, 512)
 
 
 def cnblock_pack(w1, w2, gamma=None, backward=False):

@@ -165,7 +165,9 @@ class ConvNextTower(nn.Module):
             for bi, blk in enumerate(f[1 + 2 * si]):
                 key = f"{si}.{bi}"
                 d = K.dwconv7(x, wc[key + ".w49"], blk.block[0].bias.data, n, h, w_, C)
-                if key + ".mlp" in wc:          # LN + Linear + GELU + Linear + layer scale + residual in one launch
+                # LN + Linear + GELU + Linear + layer scale + residual in one launch (C = 512, ConvNeXt-B stage 3: only when nothing
+                # is saved for a backward - with the 4C-wide pre-activation store it is no faster than the GEMM pair)
+                if key + ".mlp" in wc and (C <= 384 or not save):
                     keep = save and key + ".mlpb" not in wc      # the fused backward recomputes the hidden row
                     xn, hpre, mean, rstd = K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS,
                                                              wc[key + ".mlp"], blk.block[3].bias.data, blk.block[5].bias.data,

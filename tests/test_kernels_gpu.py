@@ -230,7 +230,7 @@ def test_attention_long_fwd_bwd(dev, B, S, heads, masked):
         _close(lse, lse2, 1e-4, 1e-4)
 
 
-@pytest.mark.parametrize("C,M", [(96, 128 * 5 + 37), (192, 300), (128, 129), (256, 200), (384, 128 * 2 + 19)])
+@pytest.mark.parametrize("C,M", [(96, 128 * 5 + 37), (192, 300), (128, 129), (256, 200), (384, 128 * 2 + 19), (512, 150)])
 def test_fused_cnblock_mlp_forward_matches_unfused_reference(dev, C, M):
     """mmg_cnblock_mlp_fwd = LN -> Linear(C,4C) -> GELU -> Linear(4C,C) -> layer scale -> + residual in one launch
     (torchvision CNBlock.block[2..5]); fp32 torch of the same op on the same bf16 inputs / bf16-rounded weights."""

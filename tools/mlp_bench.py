@@ -5,7 +5,7 @@ import torch
 from mmgclip import kernels as K, linalg as L
 
 dev = torch.device("cuda")
-for C, px, n in ((96, 256 * 256, 64), (192, 128 * 128, 64), (384, 64 * 64, 64)):
+for C, px, n in ((96, 256 * 256, 64), (192, 128 * 128, 64), (384, 64 * 64, 64), (512, 64 * 64, 32)):
     M = px * n
     g = torch.Generator().manual_seed(0)
     xd = torch.randn(M // 64, C, generator=g).to(torch.bfloat16).repeat(64, 1).to(dev)
