@@ -48,7 +48,7 @@ def build(args, comm):
     cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf", [
         f"networks={net}", f"tokenizer=bert_clinical_seqlen={args.seq_len}", "networks/dropout=dropout0",
         f"networks.image_encoder.micro_batch={args.micro_batch}", f"networks.image_encoder.image_size={args.image_size}",
-        "optimizer.config.fused=true"])
+        "optimizer.config.fused=true"] + (["networks.image_encoder.checkpoint=true"] if args.checkpoint and args.variant != "vit_b16" else []))
     seeding(cfg.base.seed)
     model = MMGCLIP(cfg)
     model.train()
@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=64)
     ap.add_argument("--variant", default="tiny", choices=["tiny", "base", "vit_b16"],
                     help="image tower: ConvNeXt-T (headline C2), ConvNeXt-B (C5 shape, bf16), ViT-B/16 (C4 shape)")
+    ap.add_argument("--checkpoint", action="store_true", help="gradient checkpointing of the image tower (micro-batch granularity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")

@@ -84,12 +84,13 @@ class _TorchvisionLayout(nn.Module):
 class ConvNextTower(nn.Module):
     """pixels fp32 [n, Cin, H, W] in [0,1] (scale16=True applies the reference's 16-bit scaling) -> features [n, dims[-1]]."""
 
-    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=64, fused_mlp=None):
+    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=64, fused_mlp=None, checkpoint=False):
         super().__init__()
         self.variant, self.in_chans, self.scale16, self.micro_batch = variant, in_chans, scale16, micro_batch
         # narrow stages (C <= 256) run the CNBlock MLP as one fused launch; MMG_FUSED_MLP=0 keeps the GEMM pair
         self.fused_mlp = (os.environ.get("MMG_FUSED_MLP", "1") != "0") if fused_mlp is None else bool(fused_mlp)
         self.fused_bwd_saved_h = os.environ.get("MMG_FUSED_MLP_BWD_SAVED_H", "0") == "1"
+        self.checkpoint = checkpoint        # recompute each micro-batch's forward in the backward (north-star config C5)
         self.dims, self.depths = CONFIGS[variant]["dims"], CONFIGS[variant]["depths"]
         self.model = _TorchvisionLayout(variant, in_chans)
         self.model_output_dimension = self.dims[-1]
@@ -318,10 +319,13 @@ class _ConvNextFn(torch.autograd.Function):
         save = anchor is not None
         feats, saved = [], []
         mb = tower.micro_batch
+        ckpt = save and tower.checkpoint
         for i in range(0, images.shape[0], mb):
-            ft, sv = tower._forward_mb(images[i:i + mb], save)
+            ft, sv = tower._forward_mb(images[i:i + mb], save and not ckpt)
             feats.append(ft)
-            saved.append(sv)
+            # gradient checkpointing at micro-batch granularity: keep only the pixels, re-run the micro-batch's forward (with its
+            # activations saved) right before its backward - activation memory becomes one micro-batch instead of the whole batch
+            saved.append({"recompute": images[i:i + mb]} if ckpt else sv)
         ctx.tower, ctx.saved_mb = tower, saved if save else None
         return torch.cat(feats, 0) if len(feats) > 1 else feats[0]
 
@@ -333,6 +337,8 @@ class _ConvNextFn(torch.autograd.Function):
         dfeat = dfeat.float().contiguous()
         i = 0
         for sv in ctx.saved_mb:
+            if "recompute" in sv:
+                _, sv = tower._forward_mb(sv["recompute"], True)
             n = sv["shape"][0]
             tower._backward_mb(dfeat[i:i + n].contiguous(), sv, tmp)
             sv.clear()

@@ -409,3 +409,33 @@ def test_resnet50_layer4_block_train_mode_forward_backward(dev, bi):
         if not (c > 0.99 and r < 0.15):          # three bf16-stored gradient stages deep for conv1 / bn1
             bad[k] = (r, c)
     assert not bad, bad
+
+
+def test_convnext_gradient_checkpointing_equals_plain_backward(dev):
+    """checkpoint=True keeps only the pixels and re-runs each micro-batch's forward before its backward: same features, same
+    gradients (up to the order of fp32 atomics), activation memory of one micro-batch."""
+    from mmgclip.networks.encoder import ConvNextTinyEncoder
+    torch.manual_seed(0)
+    img = torch.rand(8, 1, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
+    wgt = torch.randn(8, 768, generator=torch.Generator().manual_seed(2)).to(dev)
+    ref = ConvNextTinyEncoder(micro_batch=2)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    out = {}
+    for ck in (False, True):
+        tower = ConvNextTinyEncoder(micro_batch=2, checkpoint=ck)
+        tower.load_state_dict(state)
+        tower = tower.to(dev)
+        tower(img[:2]).sum().backward()                   # materialise arenas / working copies before measuring
+        tower.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        feat = tower(img)
+        held = torch.cuda.memory_allocated() - base         # activations kept between forward and backward
+        (feat * wgt).sum().backward()
+        out[ck] = (feat.detach().clone(), {n: p.grad.detach().clone() for n, p in tower.model.named_parameters()}, held)
+        del tower, feat
+    assert _rel(out[True][0], out[False][0])[0] < 1e-5
+    for n, g in out[True][1].items():
+        assert _rel(g, out[False][1][n])[0] < 2e-3, n
+    assert out[True][2] < 0.25 * out[False][2], (out[True][2], out[False][2])
