@@ -154,7 +154,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    comm = distributed.init_from_env(args.backend) if world > 1 else None
+    # MMG_SINGLE_RANK_COMM=1: N=1 with a one-rank RCCL group whose exchanges still run (rehearsal of the N>1 code path)
+    single = world == 1 and os.environ.get("MMG_SINGLE_RANK_COMM") == "1"
+    if single:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k, v)
+    comm = distributed.init_from_env(args.backend, single_rank=single) if (world > 1 or single) else None
     rank = comm.rank if comm else 0
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)

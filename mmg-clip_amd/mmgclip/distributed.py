@@ -16,10 +16,17 @@ import torch.distributed as dist
 
 
 class Comm:
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_exchange=False):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        # a one-rank group normally skips every exchange; `always_exchange` keeps them (how the RCCL calls, their
+        # stream ordering and buffer contracts are exercised on a one-GPU box: tests/test_distributed_gpu.py)
+        self.always_exchange = always_exchange
+
+    @property
+    def active(self):
+        return self.world_size > 1 or self.always_exchange
 
     def all_gather_rows(self, t):
         """[n, ...] -> [world*n, ...] in rank order (no autograd: gradients are formed locally, see head.FusedClipLoss)."""
@@ -36,10 +43,11 @@ class Comm:
         return t
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's environment; returns Comm or None when WORLD_SIZE <= 1."""
+def init_from_env(backend=None, single_rank=False):
+    """Initialise the default process group from torchrun's environment; returns Comm or None when WORLD_SIZE <= 1
+    (`single_rank=True`: build the one-rank group anyway and keep its exchanges — rehearsal of the RCCL path)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not single_rank:
         return None
     if not dist.is_initialized():
         if backend is None:
@@ -51,7 +59,7 @@ def init_from_env(backend=None):
             if backend == "nccl":           # bind the communicator to this rank's GPU up front (no lazy device guess)
                 kw["device_id"] = torch.device("cuda", idx)
         dist.init_process_group(backend=backend, **kw)
-    return Comm()
+    return Comm(always_exchange=single_rank and world <= 1)
 
 
 class GradSync:
@@ -66,7 +74,7 @@ class GradSync:
 
     def reduce_arena_async(self, arena):
         """Call when this arena's backward has been enqueued on the current stream."""
-        if self.comm is None or self.comm.world_size == 1:
+        if self.comm is None or not self.comm.active:
             return
         if self.side is None:
             self.comm.all_reduce_sum(arena.grad)
@@ -82,7 +90,7 @@ class GradSync:
 
     def finish(self):
         """Reduce the leftovers (projection heads, logit_scale) as ONE coalesced buffer and join the side stream."""
-        if self.comm is None or self.comm.world_size == 1:
+        if self.comm is None or not self.comm.active:
             return
         grads = [p.grad for p in self.extra if p.grad is not None]
         if grads:

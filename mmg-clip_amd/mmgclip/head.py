@@ -167,7 +167,7 @@ class FusedClipLoss(torch.autograd.Function):
         img, txt = _f32c(img), _f32c(txt)
         scale = _f32c(scale.reshape(1))
         n_loc, D = img.shape
-        if comm is None or comm.world_size == 1:
+        if comm is None or not comm.active:
             img_all, txt_all, off, N = img, txt, 0, n_loc
         else:
             img_all, txt_all = comm.all_gather_rows(img), comm.all_gather_rows(txt)
@@ -175,7 +175,7 @@ class FusedClipLoss(torch.autograd.Function):
         lse_i, pos_i = be.rows_forward(img, txt_all, scale, off)
         lse_t, pos_t = be.rows_forward(txt, img_all, scale, off)
         loss = be.loss_sum(lse_i, pos_i, lse_t, pos_t, 1.0 / (2.0 * N))
-        if comm is not None and comm.world_size > 1:
+        if comm is not None and comm.active:
             lse_i_all, lse_t_all = comm.all_gather_rows(lse_i), comm.all_gather_rows(lse_t)
             loss = comm.all_reduce_sum(loss)
         else:

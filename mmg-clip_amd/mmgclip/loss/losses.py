@@ -18,7 +18,7 @@ class CLIPLoss(nn.Module):
         self.comm = comm          # mmgclip.distributed.Comm for the global-batch loss (None = local batch)
 
     def forward(self, logits_per_image=None, logits_per_text=None, **kwargs):
-        if logits_per_image is None or (self.comm is not None and self.comm.world_size > 1):
+        if logits_per_image is None or (self.comm is not None and self.comm.active):
             ie, te, s = kwargs["image_embeddings"], kwargs["text_embeddings"], kwargs["logit_scale"]
             loss = head.fused_clip_loss(ie, te, s, self.comm)
             n = ie.shape[0]

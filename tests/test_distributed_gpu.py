@@ -101,3 +101,50 @@ def test_two_ranks_equal_one_rank_on_the_whole_batch(dev):
             assert cos > 0.999 and rel < 5e-2, (rank, name, cos, rel)
     # both ranks hold identical reduced gradients
     assert np.array_equal(results[0][2], results[1][2]) and np.array_equal(results[0][3], results[1][3])
+
+
+def _rccl_worker(port, q):
+    for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from mmgclip import distributed
+    from mmgclip.dataset.synthetic import synthetic_batch
+    try:
+        comm = distributed.init_from_env("nccl", single_rank=True)
+        assert comm.active and comm.world_size == 1 and torch.distributed.get_backend() == "nccl"
+        batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=11)
+        with_comm = _build_and_step(comm, _slice_batch(batch, slice(0, 8)))
+        plain = _build_and_step(None, _slice_batch(batch, slice(0, 8)))
+        # the raw exchanges, on the dtypes and shapes the step uses
+        rows = torch.randn(8, 512, device="cuda")
+        assert torch.equal(comm.all_gather_rows(rows), rows)
+        flat = torch.randn(1 << 22, device="cuda")
+        ref = flat.clone()
+        assert torch.equal(comm.all_reduce_sum(flat), ref)
+        torch.cuda.synchronize()
+        q.put(("ok", with_comm[0], plain[0], [float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(with_comm[1:], plain[1:])]))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:           # report instead of hanging the parent on q.get
+        import traceback
+        q.put(("error", traceback.format_exc(), repr(e), None))
+
+
+def test_rccl_one_rank_group_runs_every_exchange(dev):
+    """backend "nccl" (= RCCL) with one rank on the one GPU: the embedding / LSE all-gathers, the loss all-reduce and the
+    side-stream arena all-reduces all go through RCCL and must leave the step's loss and gradients unchanged."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    status, l_comm, l_plain, rels = q.get(timeout=300)
+    p.join(timeout=120)
+    assert status == "ok", l_comm
+    assert p.exitcode == 0
+    assert abs(l_comm - l_plain) < 1e-5 * abs(l_plain), (l_comm, l_plain)
+    assert max(rels) < 1e-3, rels          # atomics in the weight-gradient reductions reorder fp32 sums
