@@ -48,7 +48,8 @@ def build(args, comm):
     cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf", [
         f"networks={net}", f"tokenizer=bert_clinical_seqlen={args.seq_len}", "networks/dropout=dropout0",
         f"networks.image_encoder.micro_batch={args.micro_batch}", f"networks.image_encoder.image_size={args.image_size}",
-        "optimizer.config.fused=true"] + (["networks.image_encoder.checkpoint=true"] if args.checkpoint and args.variant != "vit_b16" else []))
+        "optimizer.config.fused=true"] + (["networks.image_encoder.checkpoint=true"] if args.checkpoint and args.variant != "vit_b16" else [])
+        + (["networks.image_encoder.fp8=true"] if args.fp8 and args.variant != "vit_b16" else []))
     seeding(cfg.base.seed)
     model = MMGCLIP(cfg)
     model.train()
@@ -138,6 +139,7 @@ def main():
     ap.add_argument("--variant", default="tiny", choices=["tiny", "base", "vit_b16"],
                     help="image tower: ConvNeXt-T (headline C2), ConvNeXt-B (C5 shape, bf16), ViT-B/16 (C4 shape)")
     ap.add_argument("--checkpoint", action="store_true", help="gradient checkpointing of the image tower (micro-batch granularity)")
+    ap.add_argument("--fp8", action="store_true", help="ConvNeXt blocks with C >= 512: forward pointwise GEMMs on e4m3 MFMA (config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -224,7 +226,9 @@ def main():
     out = {
         "metric": "image-text pairs/sec (global batch)", "value": round(value, 2), "unit": "image-text pairs/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 (fp8 e4m3 forward GEMMs in the C >= 512 ConvNeXt blocks)" if args.fp8 and args.variant != "vit_b16" else "bf16",
+        "data": "synthetic",
         "config": {"workload": f"{'C2' if args.variant == 'tiny' else 'C4-shape' if args.variant == 'vit_b16' else 'C5-shape'}: train_binary_class_clf, "
                                f"{'ViT-B/16' if args.variant == 'vit_b16' else 'ConvNeXt-' + args.variant} {args.image_size}x{args.image_size}x1 + BERT-base "
                                f"S={args.seq_len}, LinearProjection 768->512, CLIPLoss, AdamW, all parameters trained",

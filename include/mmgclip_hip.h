@@ -206,6 +206,28 @@ int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const
                         void* dxln, float* mean, float* rstd, float* ln_dw, float* ln_db, long long M, int C,
                         mmg_stream_t stream);
 
+/* ---- fp8 (OCP e4m3) forward GEMM path: BASELINE config C5 "ConvNeXt-base fp8 MFMA path" ---------------------------------
+ * The reference has no reduced-precision path (its towers run torch fp32, mmgclip/networks/encoder.py:53,156); these replace
+ * the same nn.Linear forwards of torchvision's CNBlock as mmg_gemm_nt_bf16 does, on v_mfma_f32_16x16x128_f8f6f4 (twice the
+ * bf16 MFMA rate, half the operand bytes).  Backward stays bf16 (saved pre-activations and bf16 weight copies). */
+
+/* C[M,N] = epilogue( alpha * (alpha_dev ? *alpha_dev : 1) * A[M,K] B[N,K]^T + bias ): A, B e4m3 bytes row-major (K contiguous,
+ * lda / ldb in bytes, multiples of 16), fp32 accumulate.  Epilogue as mmg_gemm_nt_bf16 with epi in {0 none, 1 GELU, 3 ReLU};
+ * out_kind: 0 bf16 | 1 fp32 | 2 e4m3 bytes (saturating at +-448; ldc in elements of that type).  K % 128 == 0, N % 8 == 0.
+ * alpha_dev: device scalar, e.g. scales[1] of mmg_quantize_e4m3_f32 (so weight scales never visit the host). */
+int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                    const float* bias, const float* colscale, const void* residual, int ldr, void* aux_out, int ldao,
+                    int epi, int out_kind, float alpha, const float* alpha_dev, mmg_stream_t stream);
+
+/* amax[0] = max(amax[0], max |src[i]|) (caller zeroes amax);  then  dst = e4m3(src * scale) with the power-of-two
+ * scale = 2^floor(log2(448 / amax)) (1 when amax is null / 0), scales[0] = scale, scales[1] = 1 / scale.  n % 4 == 0. */
+int mmg_absmax_f32(const float* src, long long n, float* amax, mmg_stream_t stream);
+int mmg_quantize_e4m3_f32(const float* src, long long n, const float* amax, void* dst, float* scales, mmg_stream_t stream);
+
+/* mmg_layernorm_fwd whose output row is written as e4m3 bytes (unscaled, saturating; ldy in bytes, multiple of 8). */
+int mmg_layernorm_fwd_fp8(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y8, int ldy,
+                          float* mean, float* rstd, int M, int C, mmg_stream_t stream);
+
 /* ---- ResNet-50 tower pieces (reference ResNet50Encoder, mmgclip/networks/encoder.py:57-119: torchvision resnet50 minus fc,
  * everything frozen except layer4).  NHWC bf16; convolutions = im2col + mmg_gemm_nt_bf16 (1x1: no im2col at all). ------------ */
 

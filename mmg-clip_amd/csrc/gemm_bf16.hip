@@ -38,6 +38,9 @@ struct GemmNT {
     float alpha;
     int tiles_m, tiles_n;
     int nt_store;             // stream the outputs past L2 (they are not re-read before they would be evicted anyway)
+    // fp8 path (mmg_gemm_nt_fp8): A / B hold OCP e4m3 bytes; K, lda, ldb are passed here in 2-byte units
+    int out_fp8;              // C receives e4m3 bytes (saturating), ldc in bytes
+    const float* alpha_dev;   // optional device scalar multiplied into alpha (1 / weight scale, produced on the device)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -92,14 +95,14 @@ __device__ __forceinline__ void store16(void* dst, const uint4 v, int nt) {
 
 // One output row segment of 8 columns: staged fp32 accumulators -> bias / activation / layer scale / residual -> store.
 __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* crow, int gr, int gc, const float* bias,
-                                                const float* cs, const uint4 res, const uint4 aux, bool want_aux) {
+                                                const float* cs, const uint4 res, const uint4 aux, bool want_aux, float alpha) {
     float v[8];
     const f32x4 lo = *reinterpret_cast<const f32x4*>(crow);
     const f32x4 hi = *reinterpret_cast<const f32x4*>(crow + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], g.alpha, bias[e]);
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], alpha, bias[e]);
     if (g.epi == EPI_GELU || g.epi == EPI_RELU) {
         if (g.aux_out) {
             uint4 o;
@@ -138,7 +141,10 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
     }
-    if (g.out_f32) {
+    if (g.out_fp8) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(g.C) + (size_t)gr * g.ldc + gc) =
+            make_uint2(pack4_e4m3(v[0], v[1], v[2], v[3]), pack4_e4m3(v[4], v[5], v[6], v[7]));
+    } else if (g.out_f32) {
         float* dst = reinterpret_cast<float*>(g.C) + (size_t)gr * g.ldc + gc;
         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -168,8 +174,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int NST>
+template <int BM, int BN, int BK, int WAVES_M, int NST, int F8 = 0>
 __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 128 ? 1 : 2)) void gemm_nt_kernel(const GemmNT g) {
+    static_assert(!F8 || BK == 64, "fp8 operands: one 128-byte K tile = one 16x16x128 MFMA step");
     constexpr int THREADS = WAVES_M * 128;
     constexpr int MI = 4, NI = BN / 32;                  // 16x16 fragments per wave (wave tile 64 x BN/2)
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -266,6 +273,34 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
                 if (NST > 2) __builtin_amdgcn_s_barrier(); else __syncthreads();
                 if (kt + NST - 1 < nk) stage((s + NST - 1) % NST, kt + NST - 1);
                 const char* buf = smem + s * STAGE;
+                if constexpr (F8 != 0) {
+                    // e4m3 operands: the 128 staged bytes of a row are ONE k-step of v_mfma_f32_16x16x128_f8f6f4 (32 bytes
+                    // per lane).  A lane takes the same two 16-byte pieces the bf16 loop reads for ks = 0 and 1; A and B
+                    // permute k identically, so the product is unchanged and staging / swizzle / reads stay as they are.
+                    constexpr int NJ = NI > 4 ? 4 : NI;        // B fragments live at a time (8 VGPRs each)
+                    i32x8 af[MI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const i32x4 lo = *reinterpret_cast<const i32x4*>(buf + a_frag[0] + i * 16 * BK * 2);
+                        const i32x4 hi = *reinterpret_cast<const i32x4*>(buf + a_frag[BK / 32 - 1] + i * 16 * BK * 2);
+                        af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int j0 = 0; j0 < NI; j0 += NJ) {
+                        i32x8 bfr[NJ];
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const i32x4 lo = *reinterpret_cast<const i32x4*>(buf + b_frag[0] + (j0 + j) * 16 * BK * 2);
+                            const i32x4 hi = *reinterpret_cast<const i32x4*>(buf + b_frag[BK / 32 - 1] + (j0 + j) * 16 * BK * 2);
+                            bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        }
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j)
+                                acc[i][j0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[i][j0 + j], 0, 0, 0, 0, 0, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int ks = 0; ks < BK / 32; ++ks) {
                     bf16x8 af[MI], bfr[NI];
@@ -279,6 +314,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
                         for (int j = 0; j < NI; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 }
+                }
             }
         }
     }
@@ -288,6 +324,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
     constexpr bool PREFETCH = PASSES <= 8;                // (wider tiles: 16 passes of prefetch would spill)
     uint4 res_v[PREFETCH ? PASSES : 1], aux_v[PREFETCH ? PASSES : 1];
     const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DRELU);
+    const float alpha = g.alpha_dev ? g.alpha * *g.alpha_dev : g.alpha;
 #pragma unroll
     for (int p = 0; p < (PREFETCH ? PASSES : 0); ++p) {
         const int rl = tr + (p % QP) * RPP;
@@ -332,21 +369,21 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
                 const int gr = m0 + q * 64 + rl;
                 if (rl < 64 && gr < g.M)
                     nt_epilogue_row(g, Cs + rl * LDCS + tc, gr, gc, bias, cs, PREFETCH ? res_v[PREFETCH ? q * QP + hp : 0] : rs_v[PREFETCH ? 0 : hp],
-                                    PREFETCH ? aux_v[PREFETCH ? q * QP + hp : 0] : as_v[PREFETCH ? 0 : hp], want_aux);
+                                    PREFETCH ? aux_v[PREFETCH ? q * QP + hp : 0] : as_v[PREFETCH ? 0 : hp], want_aux, alpha);
             }
         }
     }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int NST>
+template <int BM, int BN, int BK, int WAVES_M, int NST, int F8 = 0>
 static void launch_nt(GemmNT& g, hipStream_t stream) {
     g.tiles_m = cdiv(g.M, BM);
     g.tiles_n = cdiv(g.N, BN);
     const size_t stage = (size_t)NST * (BM * BK * 2 + BN * BK * 2);
     const size_t cs = (size_t)64 * (BN + 4) * 4;
     const size_t shm = stage > cs ? stage : cs;
-    mmg_allow_lds(gemm_nt_kernel<BM, BN, BK, WAVES_M, NST>, shm);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WAVES_M, NST>), dim3(g.tiles_m * g.tiles_n), dim3(WAVES_M * 128), shm,
+    mmg_allow_lds(gemm_nt_kernel<BM, BN, BK, WAVES_M, NST, F8>, shm);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WAVES_M, NST, F8>), dim3(g.tiles_m * g.tiles_n), dim3(WAVES_M * 128), shm,
                        stream, g);
 }
 
@@ -370,7 +407,7 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.bias = bias; g.colscale = colscale;
     g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = (const bf16_t*)aux_in; g.ldai = ldai;
-    g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha;
+    g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.out_fp8 = 0; g.alpha_dev = nullptr;
     static const int force_bk = getenv("MMG_GEMM_BK") ? atoi(getenv("MMG_GEMM_BK")) : 0;   // tuning knobs
     static const int use_big = getenv("MMG_GEMM_V2") ? atoi(getenv("MMG_GEMM_V2")) : 1;
     // outputs larger than the 256 MiB Infinity Cache cannot be re-read from cache anyway: stream them past L2
@@ -393,6 +430,35 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     else if (n96) { if (k64) launch_nt<128, 96, 64, 2, 2>(g, stream); else launch_nt<128, 96, 32, 2, 2>(g, stream); }
     else          { if (k64) launch_nt<128, 128, 64, 2, 2>(g, stream); else launch_nt<128, 128, 32, 2, 2>(g, stream); }
     MMG_LAUNCH_CHECK("mmg_gemm_nt_bf16");
+    return 0;
+}
+
+// e4m3 x e4m3 -> fp32 accumulate on the double-rate K = 128 MFMA; same tiles, staging and epilogues as the bf16 kernel
+// (an e4m3 row of K bytes is staged as a "bf16" row of K/2 elements).
+MMG_API int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                            const float* bias, const float* colscale, const void* residual, int ldr, void* aux_out,
+                            int ldao, int epi, int out_kind, float alpha, const float* alpha_dev, hipStream_t stream) {
+    MMG_CHECK_ARG(A && B && C, "mmg_gemm_nt_fp8: null operand");
+    MMG_CHECK_ARG(M > 0 && N > 0 && K > 0, "mmg_gemm_nt_fp8: M=%d N=%d K=%d must be positive", M, N, K);
+    MMG_CHECK_ARG(K % 128 == 0, "mmg_gemm_nt_fp8: K=%d must be a multiple of 128 (one MFMA k-step)", K);
+    MMG_CHECK_ARG(N % 8 == 0, "mmg_gemm_nt_fp8: N=%d must be a multiple of 8", N);
+    MMG_CHECK_ARG(out_kind >= 0 && out_kind <= 2, "mmg_gemm_nt_fp8: out_kind=%d (0 bf16, 1 fp32, 2 e4m3)", out_kind);
+    MMG_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && ldc % 8 == 0,
+                  "mmg_gemm_nt_fp8: leading dimensions must cover the row; lda/ldb multiples of 16 bytes, ldc of 8 "
+                  "(lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    MMG_CHECK_ARG(epi == EPI_NONE || epi == EPI_GELU || epi == EPI_RELU, "mmg_gemm_nt_fp8: epilogue %d not available", epi);
+    MMG_CHECK_ARG(!residual || (ldr >= N && ldr % 8 == 0), "mmg_gemm_nt_fp8: bad ldr=%d", ldr);
+    MMG_CHECK_ARG(!aux_out || (ldao >= N && ldao % 8 == 0), "mmg_gemm_nt_fp8: bad ldao=%d", ldao);
+    GemmNT g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
+    g.C = C; g.ldc = ldc; g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 2; g.bias = bias; g.colscale = colscale;
+    g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = nullptr; g.ldai = 0;
+    g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.alpha_dev = alpha_dev;
+    g.nt_store = (size_t)M * N * (out_kind == 1 ? 4 : out_kind == 2 ? 1 : 2) >= ((size_t)256 << 20);
+    if (N % 256 == 0 && M >= 4096) launch_nt<256, 256, 64, 4, 2, 1>(g, stream);
+    else if (M >= 4096) launch_nt<256, 128, 64, 4, 3, 1>(g, stream);
+    else launch_nt<128, 128, 64, 2, 2, 1>(g, stream);
+    MMG_LAUNCH_CHECK("mmg_gemm_nt_fp8");
     return 0;
 }
 

@@ -30,6 +30,7 @@ struct LNArgs {
     float* dgamma; float* dbeta;
     const bf16_t* add; int ldadd;    // optional residual-path gradient added to dx (pre-LN transformer blocks)
     int nt;                          // stream the output past L2 (tensor larger than the Infinity Cache)
+    int y_fp8;                       // y receives OCP e4m3 bytes (ldy in bytes): operand of the fp8 GEMM path
 };
 
 // returns (size_t)-1 for pixels of an odd last row / column: a 2x2 stride-2 convolution never reads them
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const LNArgs a) {
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mu) * rs * a.gamma[c * 8 + e] + a.beta[c * 8 + e];
-                if (obase != (size_t)-1) store16_stream(a.y + obase + c * 8, pack8(o), a.nt);
+                if (a.y_fp8)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(a.y) + obase + c * 8) =
+                        make_uint2(pack4_e4m3(o[0], o[1], o[2], o[3]), pack4_e4m3(o[4], o[5], o[6], o[7]));
+                else if (obase != (size_t)-1) store16_stream(a.y + obase + c * 8, pack8(o), a.nt);
             }
         }
         if (gl == 0) {
@@ -232,6 +236,20 @@ MMG_API int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const 
     a.nt = (size_t)M * C * 2 >= ((size_t)256 << 20);
     if (launch_ln<false>(a, stream)) return 1;
     MMG_LAUNCH_CHECK("mmg_layernorm_fwd");
+    return 0;
+}
+
+// LayerNorm whose output is written as e4m3 bytes (unscaled, saturating): the A operand of mmg_gemm_nt_fp8
+MMG_API int mmg_layernorm_fwd_fp8(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y8, int ldy,
+                                  float* mean, float* rstd, int M, int C, hipStream_t stream) {
+    if (ln_check("mmg_layernorm_fwd_fp8", M, C, 0, 0, 0)) return 1;
+    MMG_CHECK_ARG(x && gamma && beta && y8 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C,
+                  "mmg_layernorm_fwd_fp8: bad pointer or leading dimension");
+    LNArgs a = {};
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps; a.y = (bf16_t*)y8; a.ldy = ldy;
+    a.mean = mean; a.rstd = rstd; a.M = M; a.C = C; a.y_fp8 = 1;
+    if (launch_ln<false>(a, stream)) return 1;
+    MMG_LAUNCH_CHECK("mmg_layernorm_fwd_fp8");
     return 0;
 }
 

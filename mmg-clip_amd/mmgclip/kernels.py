@@ -28,6 +28,30 @@ def layernorm_fwd(x, gamma, beta, eps, patch_hw=None, want_stats=True):
     return y, mean, rstd
 
 
+def layernorm_fwd_fp8(x, gamma, beta, eps, want_stats=True):
+    """x bf16 [M,C] -> y e4m3 bytes (uint8 [M,C], unscaled, saturating), mean, rstd: operand of linalg.gemm_nt_fp8."""
+    M, C = x.shape
+    y = torch.empty(M, C, device=x.device, dtype=torch.uint8)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
+    call("mmg_layernorm_fwd_fp8", ptr(x), x.stride(0), ptr(gamma), ptr(beta), float(eps), ptr(y), y.stride(0), ptr(mean),
+         ptr(rstd), M, C, stream())
+    return y, mean, rstd
+
+
+def quantize_e4m3(w):
+    """fp32 tensor -> (e4m3 bytes uint8 of w.shape, scales fp32 [2] = (scale, 1/scale)) with the per-tensor power-of-two
+    scale 2^floor(log2(448 / max|w|)); amax and scale stay on the device."""
+    w = w.contiguous()
+    assert w.dtype == torch.float32 and w.numel() % 4 == 0
+    amax = torch.zeros(1, device=w.device, dtype=torch.float32)
+    q = torch.empty(w.shape, device=w.device, dtype=torch.uint8)
+    scales = torch.empty(2, device=w.device, dtype=torch.float32)
+    call("mmg_absmax_f32", ptr(w), w.numel(), ptr(amax), stream())
+    call("mmg_quantize_e4m3_f32", ptr(w), w.numel(), ptr(amax), ptr(q), ptr(scales), stream())
+    return q, scales
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, patch_hw=None, out=None, add=None):
     M, C = x.shape
     dx = out if out is not None else torch.empty(M, C, device=x.device, dtype=BF16)

@@ -27,6 +27,24 @@ def gemm_nt(a, b, out=None, bias=None, colscale=None, residual=None, aux_in=None
     return out
 
 
+OUT_BF16, OUT_F32, OUT_E4M3 = 0, 1, 2
+
+
+def gemm_nt_fp8(a, b, out=None, bias=None, colscale=None, residual=None, aux_out=None, epi=EPI_NONE, out_kind=OUT_BF16,
+                alpha=1.0, alpha_dev=None):
+    """out[M,N] = epilogue(alpha * alpha_dev * a[M,K] @ b[N,K].T + bias), a / b e4m3 bytes (uint8) — include/mmgclip_hip.h."""
+    assert a.dtype == torch.uint8 and b.dtype == torch.uint8
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=(torch.bfloat16, torch.float32, torch.uint8)[out_kind])
+    call("mmg_gemm_nt_fp8", ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out), M, N, K, ptr(bias), ptr(colscale),
+         ptr(residual), _ld(residual) if residual is not None else 0, ptr(aux_out),
+         _ld(aux_out) if aux_out is not None else 0, epi, out_kind, float(alpha), ptr(alpha_dev), stream())
+    return out
+
+
 def gemm_tn_acc(a, b, out, alpha=1.0, colsum=None):
     """out[N1,N2] (fp32) += alpha * a[M,N1].T @ b[M,N2];  colsum[N1] (fp32, optional) += alpha * a.sum(0)."""
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and out.dtype == torch.float32
@@ -62,6 +80,19 @@ def gemm_nt(a, b, out=None, **kw):       # noqa: F811  (profiling shim around th
         if kw.get(extra) is not None:
             nbytes += 2 * M * N
     return PROFILE.timed("gemm_nt_kernel", 2.0 * M * N * K, nbytes, lambda: _gemm_nt_raw(a, b, out=out, **kw))
+
+
+_gemm_nt_fp8_raw = gemm_nt_fp8
+
+
+def gemm_nt_fp8(a, b, out=None, **kw):       # noqa: F811
+    if not PROFILE.on:
+        return _gemm_nt_fp8_raw(a, b, out=out, **kw)
+    M, K = a.shape
+    N = b.shape[0]
+    esz = (2, 4, 1)[kw.get("out_kind", OUT_BF16)]
+    nbytes = (M * K + N * K) + esz * M * N + sum(2 * M * N for extra in ("residual", "aux_out") if kw.get(extra) is not None)
+    return PROFILE.timed("gemm_nt_fp8_kernel", 2.0 * M * N * K, nbytes, lambda: _gemm_nt_fp8_raw(a, b, out=out, **kw))
 
 
 def gemm_tn_acc(a, b, out, alpha=1.0, colsum=None):       # noqa: F811

@@ -84,13 +84,19 @@ class _TorchvisionLayout(nn.Module):
 class ConvNextTower(nn.Module):
     """pixels fp32 [n, Cin, H, W] in [0,1] (scale16=True applies the reference's 16-bit scaling) -> features [n, dims[-1]]."""
 
-    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=64, fused_mlp=None, checkpoint=False):
+    def __init__(self, variant="tiny", in_chans=1, scale16=True, micro_batch=64, fused_mlp=None, checkpoint=False, fp8=False,
+                 fp8_min_channels=None):
         super().__init__()
         self.variant, self.in_chans, self.scale16, self.micro_batch = variant, in_chans, scale16, micro_batch
         # narrow stages (C <= 256) run the CNBlock MLP as one fused launch; MMG_FUSED_MLP=0 keeps the GEMM pair
         self.fused_mlp = (os.environ.get("MMG_FUSED_MLP", "1") != "0") if fused_mlp is None else bool(fused_mlp)
         self.fused_bwd_saved_h = os.environ.get("MMG_FUSED_MLP_BWD_SAVED_H", "0") == "1"
         self.checkpoint = checkpoint        # recompute each micro-batch's forward in the backward (north-star config C5)
+        # fp8 (config C5): the two pointwise GEMMs of every block with C % 128 == 0 and C >= fp8_min_channels run their FORWARD
+        # on e4m3 operands (LayerNorm / GELU outputs cast unscaled, weights with a per-tensor power-of-two scale); the backward
+        # stays bf16 on the saved pre-activation.  Default 512: the stages whose blocks are GEMM pairs anyway.
+        self.fp8 = bool(fp8)
+        self.fp8_min_channels = int(os.environ.get("MMG_FP8_MIN_C", "512")) if fp8_min_channels is None else int(fp8_min_channels)
         self.dims, self.depths = CONFIGS[variant]["dims"], CONFIGS[variant]["depths"]
         self.model = _TorchvisionLayout(variant, in_chans)
         self.model_output_dimension = self.dims[-1]
@@ -112,6 +118,9 @@ class ConvNextTower(nn.Module):
     @property
     def arena(self):
         return self._arena
+
+    def _fp8_block(self, C):
+        return self.fp8 and C % 128 == 0 and C >= self.fp8_min_channels
 
     def _refresh_working_copies(self):
         """bf16 / transposed / tap-major copies the kernels read; rebuilt only when a parameter changed."""
@@ -135,7 +144,10 @@ class ConvNextTower(nn.Module):
                 wc[key + ".w2"] = K.cast_bf16(blk.block[5].weight.data)                      # [C, 4C]
                 wc[key + ".w2gt"] = K.transpose_cast_bf16(blk.block[5].weight.data,          # [4C, C] * gamma
                                                           blk.layer_scale.data.reshape(C))
-                if self.fused_mlp and K.cnblock_supported(C):                                # packed LDS images
+                if self._fp8_block(C):                                                       # e4m3 bytes + (scale, 1/scale)
+                    wc[key + ".w1f8"], wc[key + ".s1"] = K.quantize_e4m3(blk.block[3].weight.data)
+                    wc[key + ".w2f8"], wc[key + ".s2"] = K.quantize_e4m3(blk.block[5].weight.data)
+                elif self.fused_mlp and K.cnblock_supported(C):                              # packed LDS images
                     wc[key + ".mlp"] = K.cnblock_pack(blk.block[3].weight.data, blk.block[5].weight.data)
                     mode = K.cnblock_bwd_mode(C)     # 1: hidden row recomputed; 2: reads the forward's saved pre-activation
                     if mode == 2 and not self.fused_bwd_saved_h:   # (C=384: slower than the GEMM pair so far)
@@ -177,11 +189,18 @@ class ConvNextTower(nn.Module):
                         saved[key] = (x, d, mean, rstd, hpre)
                     x = xn
                     continue
-                ln, mean, rstd = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=save)
                 hpre = torch.empty(x.shape[0], 4 * C, device=x.device, dtype=torch.bfloat16) if save else None
-                g = L.gemm_nt(ln, wc[key + ".w1"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre)
-                xn = L.gemm_nt(g, wc[key + ".w2"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
-                               residual=x)
+                if key + ".w1f8" in wc:      # e4m3 operands, fp32 accumulate; the saved pre-activation stays bf16
+                    ln, mean, rstd = K.layernorm_fwd_fp8(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=save)
+                    g = L.gemm_nt_fp8(ln, wc[key + ".w1f8"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre,
+                                      out_kind=L.OUT_E4M3, alpha_dev=wc[key + ".s1"][1:])
+                    xn = L.gemm_nt_fp8(g, wc[key + ".w2f8"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
+                                       residual=x, alpha_dev=wc[key + ".s2"][1:])
+                else:
+                    ln, mean, rstd = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=save)
+                    g = L.gemm_nt(ln, wc[key + ".w1"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre)
+                    xn = L.gemm_nt(g, wc[key + ".w2"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
+                                   residual=x)
                 if save:
                     saved[key] = (x, d, mean, rstd, hpre)
                 del ln, g

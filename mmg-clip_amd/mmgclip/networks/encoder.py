@@ -81,8 +81,9 @@ class _ConvNextEncoder(ConvNextTower):
     VARIANT = "tiny"
 
     def __init__(self, pretrained=None, image_features_dimension=None, in_chans=1, scale16=True, micro_batch=64, freeze=False,
-                 checkpoint=False):
-        super().__init__(self.VARIANT, in_chans=in_chans, scale16=scale16, micro_batch=micro_batch, checkpoint=checkpoint)
+                 checkpoint=False, fp8=False):
+        super().__init__(self.VARIANT, in_chans=in_chans, scale16=scale16, micro_batch=micro_batch, checkpoint=checkpoint,
+                         fp8=fp8)
         if isinstance(pretrained, str) and os.path.isfile(pretrained):
             sd = _load_state_file(pretrained)
             sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()}

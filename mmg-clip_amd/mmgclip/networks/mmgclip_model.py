@@ -52,7 +52,7 @@ class MMGCLIP(nn.Module):
                 in_chans=_get(ie, "in_chans", 1), scale16=_get(ie, "scale16", True), micro_batch=_get(ie, "micro_batch", 64),
                 freeze=_get(ie, "freeze", False),
                 **({"image_size": _get(ie, "image_size", 224)} if enc_name == "ViTB16Encoder" else
-                   {"checkpoint": _get(ie, "checkpoint", False)})).to(self.device)
+                   {"checkpoint": _get(ie, "checkpoint", False), "fp8": _get(ie, "fp8", False)})).to(self.device)
             logger.info(f"Using {self.image_encoder.__class__.__name__}")
 
         te = self.config.networks.text_encoder

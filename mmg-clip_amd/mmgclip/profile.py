@@ -6,6 +6,7 @@ written once.  Off by default: a disabled profiler costs one attribute test per 
 import torch
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0       # dense e4m3 on the K = 128 MFMA, same guide
 HBM_PEAK_GBS = 8000.0
 
 
@@ -45,10 +46,11 @@ class KernelProfile:
 
     def roofline(self, family, stats):
         """The bench.py `roofline` object for one family: the bound is whichever peak the launch sits closer to."""
-        f_mfma = stats["tflops"] / MFMA_BF16_PEAK_TFLOPS
+        peak = MFMA_FP8_PEAK_TFLOPS if "fp8" in family else MFMA_BF16_PEAK_TFLOPS
+        f_mfma = stats["tflops"] / peak
         f_hbm = stats["gbytes_per_s"] / HBM_PEAK_GBS
         if f_mfma >= f_hbm:
-            r = {"bound": "mfma", "achieved": stats["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f_mfma, 4)}
+            r = {"bound": "mfma", "achieved": stats["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(f_mfma, 4)}
         else:
             r = {"bound": "hbm", "achieved": stats["gbytes_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}
         r.update({"kernel": family, "traffic": None, "launches": stats["launches"], "avg_launch_us": stats["avg_launch_us"],

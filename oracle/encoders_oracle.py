@@ -12,12 +12,34 @@ the reference's call sites:
 tests/test_oracle_encoders.py cross-checks the BERT restatement against the installed transformers BertModel (eager
 attention, dropout 0) and the ConvNeXt geometry against the notebook's printed shapes ([1,1,1906,818] -> [1,768,59,25]).
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
 
-def convnext_forward(sd, images, depths=(3, 3, 9, 3), scale16=True, prefix="features."):
-    """torchvision ConvNeXt `features` + `avgpool` from a state dict (fp32).  images [n,Cin,H,W]; returns [n,C,1,1]."""
+def q_e4m3(t):
+    """Round to OCP e4m3 (round-to-nearest-even, saturating at +-448) and back to fp32: the value an e4m3 byte holds."""
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def q_e4m3_weight(w):
+    """Per-tensor power-of-two scaling as csrc/fp8_ops.hip: scale = 2^floor(log2(448 / max|w|)); returns the dequantised weight
+    (exact in fp32: the scale is a power of two)."""
+    amax = float(w.detach().abs().max())
+    scale = 1.0
+    if 0.0 < amax < 3.0e38:
+        scale = 2.0 ** math.floor(math.log2(448.0 / amax))
+        if amax * scale > 448.0:
+            scale *= 0.5
+    return q_e4m3(w * scale) / scale
+
+
+def convnext_forward(sd, images, depths=(3, 3, 9, 3), scale16=True, prefix="features.", fp8_min_channels=None):
+    """torchvision ConvNeXt `features` + `avgpool` from a state dict (fp32).  images [n,Cin,H,W]; returns [n,C,1,1].
+    fp8_min_channels: blocks with C % 128 == 0 and C >= that value run their two Linear layers on e4m3 operands (LayerNorm and
+    GELU outputs rounded to e4m3 unscaled, weights per-tensor scaled), fp32 accumulation - BASELINE config C5's forward; the
+    rounding is a straight-through identity for autograd, as the bf16 backward of the build treats it."""
     x = images
     if scale16:
         x = 65535.0 * x
@@ -39,9 +61,16 @@ def convnext_forward(sd, images, depths=(3, 3, 9, 3), scale16=True, prefix="feat
             y = F.conv2d(x, g(k + "block.0.weight"), g(k + "block.0.bias"), padding=3, groups=C)
             y = y.permute(0, 2, 3, 1)
             y = F.layer_norm(y, (C,), g(k + "block.2.weight"), g(k + "block.2.bias"), 1e-6)
-            y = F.linear(y, g(k + "block.3.weight"), g(k + "block.3.bias"))
-            y = F.gelu(y)
-            y = F.linear(y, g(k + "block.5.weight"), g(k + "block.5.bias"))
+            if fp8_min_channels is not None and C % 128 == 0 and C >= fp8_min_channels:
+                ste = lambda t, q: t + (q - t).detach()                    # noqa: E731  value of q, gradient of t
+                w1, w2 = g(k + "block.3.weight"), g(k + "block.5.weight")
+                y = F.linear(ste(y, q_e4m3(y)), ste(w1, q_e4m3_weight(w1)), g(k + "block.3.bias"))
+                y = F.gelu(y)
+                y = F.linear(ste(y, q_e4m3(y)), ste(w2, q_e4m3_weight(w2)), g(k + "block.5.bias"))
+            else:
+                y = F.linear(y, g(k + "block.3.weight"), g(k + "block.3.bias"))
+                y = F.gelu(y)
+                y = F.linear(y, g(k + "block.5.weight"), g(k + "block.5.bias"))
             y = y.permute(0, 3, 1, 2)
             x = x + g(k + "layer_scale") * y             # stochastic depth p = 0
         if si < 3:

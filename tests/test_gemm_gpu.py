@@ -95,3 +95,74 @@ def test_colsum(dev):
         out = torch.zeros(N, device=dev)
         linalg.colsum_acc(a, out)
         np.testing.assert_allclose(out.cpu().numpy(), a.float().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+# ---- fp8 (OCP e4m3) NT GEMM ------------------------------------------------------------------------------------------------
+def _e4m3_bytes(shape, seed, scale=1.0):
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+    q = x.clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), q.to(torch.float64)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 136, 128), (4096, 256, 512), (4200, 512, 2048), (4100, 384, 256)])
+def test_nt_fp8_plain(dev, M, N, K):
+    """all three tile configurations (128x128, 256x128, 256x256), ragged M / N, fp32 output."""
+    from mmgclip import linalg as L
+    a8, a = _e4m3_bytes((M, K), 1)
+    b8, b = _e4m3_bytes((N, K), 2)
+    ref = a @ b.T
+    out = L.gemm_nt_fp8(a8.to(dev), b8.to(dev), out_kind=L.OUT_F32).cpu().double()
+    err = float((out - ref).abs().max() / ref.abs().max())
+    # the K = 128 MFMA aligns the 128 products of a step to their largest exponent before adding (measured 2e-5 of the output
+    # range on random data; exact on the integer test below), so this is not an fp32 dot product to the last bit
+    assert err < 1e-4, err
+
+
+def test_nt_fp8_integer_exact_asymmetric(dev):
+    """small integers are exact in e4m3 and in the fp32 accumulator: a swapped / permuted operand map cannot hide."""
+    from mmgclip import linalg as L
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(-4, 5, (320, 256), generator=g).float()
+    b = torch.randint(-4, 5, (264, 256), generator=g).float()
+    b[:, :128] *= 2                                          # the two 64-byte halves of a k-step weigh differently
+    out = L.gemm_nt_fp8(a.to(torch.float8_e4m3fn).view(torch.uint8).to(dev), b.to(torch.float8_e4m3fn).view(torch.uint8).to(dev),
+                        out_kind=L.OUT_F32).cpu()
+    assert torch.equal(out, a @ b.T)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 384, 128), (4200, 512, 384)])
+def test_nt_fp8_epilogues(dev, M, N, K):
+    """bias + GELU with the bf16 pre-activation side output and an e4m3 result; then scale (device alpha) + layer scale + residual."""
+    from mmgclip import linalg as L
+    from oracle.encoders_oracle import q_e4m3
+    a8, a = _e4m3_bytes((M, K), 4)
+    b8, b = _e4m3_bytes((N, K), 5)
+    g = torch.Generator().manual_seed(6)
+    bias = torch.randn(N, generator=g)
+    cs = torch.rand(N, generator=g) + 0.5
+    res = torch.randn(M, N, generator=g).bfloat16()
+    alpha_dev = torch.tensor([0.03125], device=dev)
+    pre_ref = (a @ b.T) * (0.25 * 0.03125) + bias.double()
+    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    h8 = L.gemm_nt_fp8(a8.to(dev), b8.to(dev), bias=bias.to(dev), epi=L.EPI_GELU, aux_out=aux, out_kind=L.OUT_E4M3, alpha=0.25,
+                       alpha_dev=alpha_dev)
+    assert h8.dtype == torch.uint8
+    assert float((aux.cpu().double() - pre_ref).abs().max()) < 1e-2 * float(pre_ref.abs().max())       # bf16 storage
+    h_ref = q_e4m3(torch.nn.functional.gelu(pre_ref).float())
+    h = h8.cpu().view(torch.float8_e4m3fn).float()
+    # an e4m3 step is 6-12 % of the value: a result on a rounding boundary may land on either neighbour, never further
+    mism = (h != h_ref)
+    assert float(mism.float().mean()) < 5e-3, float(mism.float().mean())
+    assert bool(((h - h_ref).abs() <= torch.maximum(0.126 * torch.maximum(h.abs(), h_ref.abs()), torch.tensor(2.0 ** -9))).all())
+    out = L.gemm_nt_fp8(a8.to(dev), b8.to(dev), bias=bias.to(dev), colscale=cs.to(dev), residual=res.to(dev), alpha=0.25,
+                        alpha_dev=alpha_dev)
+    ref = pre_ref * cs.double() + res.double()
+    assert out.dtype == torch.bfloat16
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-2 * float(ref.abs().max())
+
+
+def test_nt_fp8_rejects_bad_k(dev):
+    from mmgclip import linalg as L
+    a = torch.zeros(128, 96, device=dev, dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        L.gemm_nt_fp8(a, a)

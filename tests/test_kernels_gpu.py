@@ -1,4 +1,6 @@
 """HBM-bound / conv / attention kernels vs plain PyTorch fp32 references of the same ops (bf16-rounded inputs)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -317,3 +319,70 @@ def test_fused_cnblock_mlp_backward_with_layernorm_backward(dev, C, M):
     _close(dd, dx_want, 3e-2, 3e-2)
     rel = lambda a, b: float((a.cpu() - b).norm() / b.norm())   # noqa: E731
     assert rel(dw - 0.5, dw_want) < 2e-2 and rel(db + 0.25, db_want) < 2e-2, (rel(dw - 0.5, dw_want), rel(db + 0.25, db_want))
+
+
+# ---- fp8 (e4m3) operand producers --------------------------------------------------------------------------------------------
+def test_quantize_e4m3_matches_the_oracle_bytes(dev):
+    """scale is a power of two, so src * scale is exact: bytes and scales must equal the oracle's bit for bit."""
+    from mmgclip import kernels as K
+    from oracle.encoders_oracle import q_e4m3_weight
+    for seed, std, shape in ((0, 0.02, (512, 128)), (1, 3.0, (96, 384)), (2, 1e-4, (64, 64))):
+        w = torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * std
+        q, scales = K.quantize_e4m3(w.to(dev))
+        s, inv = scales.cpu().tolist()
+        assert s * inv == 1.0 and math.log2(s) == round(math.log2(s))
+        amax = float(w.abs().max())
+        assert 224.0 < amax * s <= 448.0
+        deq = q.cpu().view(torch.float8_e4m3fn).float() * inv
+        assert torch.equal(deq, q_e4m3_weight(w))
+    z, scales = K.quantize_e4m3(torch.zeros(8, 8, device=dev))
+    assert scales.cpu().tolist() == [1.0, 1.0] and int(z.max()) == 0
+
+
+def test_layernorm_fwd_fp8_bytes(dev):
+    from mmgclip import kernels as K
+    from oracle.encoders_oracle import q_e4m3
+    for M, C in ((1000, 128), (520, 512), (77, 1024)):
+        g = torch.Generator().manual_seed(C)
+        x = (torch.randn(M, C, generator=g) * 3 + 1).bfloat16()
+        w, b = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        y8, mean, rstd = K.layernorm_fwd_fp8(x.to(dev), w.to(dev), b.to(dev), 1e-6)
+        ref32 = torch.nn.functional.layer_norm(x.float(), (C,), w, b, 1e-6)
+        ref = q_e4m3(ref32)
+        y = y8.cpu().view(torch.float8_e4m3fn).float()
+        mism = y != ref
+        assert float(mism.float().mean()) < 5e-3                      # boundary cases only (fp32 LN evaluated in another order)
+        assert bool(((y - ref).abs() <= torch.maximum(0.126 * torch.maximum(y.abs(), ref.abs()), torch.tensor(2.0 ** -9))).all())
+        assert float((mean.cpu() - x.float().mean(1)).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("M,C", [(600, 512), (4200, 256), (300, 1024)])
+def test_cnblock_fp8_forward_one_block(dev, M, C):
+    """LayerNorm -> e4m3, Linear(e4m3 x e4m3) + GELU -> e4m3, Linear + layer scale + residual on identical bf16 inputs: with the
+    same values at every rounding point the device must reproduce the oracle's e4m3 arithmetic to bf16 storage accuracy, far
+    below the distance between the e4m3 and the fp32 block."""
+    from mmgclip import kernels as K, linalg as L
+    from oracle.encoders_oracle import q_e4m3, q_e4m3_weight
+    g = torch.Generator().manual_seed(C + M)
+    d = (torch.randn(M, C, generator=g) * 2 + 0.5).bfloat16()
+    x = torch.randn(M, C, generator=g).bfloat16()
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w1, b1 = torch.randn(4 * C, C, generator=g) * 0.05, 0.1 * torch.randn(4 * C, generator=g)
+    w2, b2 = torch.randn(C, 4 * C, generator=g) * 0.05, 0.1 * torch.randn(C, generator=g)
+    gamma = 0.3 + 0.7 * torch.rand(C, generator=g)
+    # oracle
+    ln = F.layer_norm(d.float(), (C,), lw, lb, 1e-6)
+    hpre_o = F.linear(q_e4m3(ln), q_e4m3_weight(w1), b1)
+    y_o = F.linear(q_e4m3(F.gelu(hpre_o)), q_e4m3_weight(w2), b2) * gamma + x.float()
+    y_32 = F.linear(F.gelu(F.linear(ln, w1, b1)), w2, b2) * gamma + x.float()
+    # device
+    ln8, _, _ = K.layernorm_fwd_fp8(d.to(dev), lw.to(dev), lb.to(dev), 1e-6, want_stats=False)
+    w18, s1 = K.quantize_e4m3(w1.to(dev))
+    w28, s2 = K.quantize_e4m3(w2.to(dev))
+    hpre = torch.empty(M, 4 * C, device=dev, dtype=torch.bfloat16)
+    h8 = L.gemm_nt_fp8(ln8, w18, bias=b1.to(dev), epi=L.EPI_GELU, aux_out=hpre, out_kind=L.OUT_E4M3, alpha_dev=s1[1:])
+    y = L.gemm_nt_fp8(h8, w28, bias=b2.to(dev), colscale=gamma.to(dev), residual=x.to(dev), alpha_dev=s2[1:])
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())       # noqa: E731
+    assert rel(hpre, hpre_o) < 4e-3                         # bf16 storage of the side output
+    assert rel(y, y_o) < 6e-3, rel(y, y_o)                  # bf16 storage + the rare rounding-boundary element
+    assert rel(y, y_32) > 4 * rel(y, y_o)                   # ... while e4m3 itself moves the block by several times that
