@@ -455,8 +455,9 @@ MMG_API int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void
     g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = nullptr; g.ldai = 0;
     g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.alpha_dev = alpha_dev;
     g.nt_store = (size_t)M * N * (out_kind == 1 ? 4 : out_kind == 2 ? 1 : 2) >= ((size_t)256 << 20);
-    if (N % 256 == 0 && M >= 4096) launch_nt<256, 256, 64, 4, 2, 1>(g, stream);
-    else if (M >= 4096) launch_nt<256, 128, 64, 4, 3, 1>(g, stream);
+    static const int tile = getenv("MMG_FP8_TILE") ? atoi(getenv("MMG_FP8_TILE")) : 0;   // tuning: 1 = 256x128, 2 = 128x128
+    if (tile == 0 && N % 256 == 0 && M >= 4096) launch_nt<256, 256, 64, 4, 2, 1>(g, stream);
+    else if (tile != 2 && M >= 4096) launch_nt<256, 128, 64, 4, 3, 1>(g, stream);
     else launch_nt<128, 128, 64, 2, 2, 1>(g, stream);
     MMG_LAUNCH_CHECK("mmg_gemm_nt_fp8");
     return 0;
