@@ -69,6 +69,7 @@ struct AttArgs {
     int S, S_pad, heads, Hd;             // S = row stride of a sequence (padded layout) / longest sequence (packed layout)
     const int* cu;                      // nullable: packed layout, sequence b = rows cu[b] .. cu[b+1] (all attended)
     float scale;
+    int nbh, nblk;                      // flash kernels: 1-D grid of nbh (= B * heads) x nblk row blocks
     // backward
     const bf16_t* dctx; int lddc;       // [B*S, Hd]
     bf16_t* dqkv; int lddq;             // [B*S, 3*Hd]
@@ -400,19 +401,39 @@ MMG_API int mmg_attention_varlen_bwd(const void* qkv, int ld, const int* cu_seql
 
 // =============================================================================================
 // Long sequences (ViT-B/16 at 1024x1024: S = 4097; BERT training at S > 256): flash-style tiling.
-// Same fragments and LDS images as above, but K/V (forward, dQ) or Q/dO (dK,dV) stream through LDS in 64-row tiles
-// and the softmax is computed online; nothing of size S x S exists anywhere.  One workgroup = (sequence, head,
-// 64-row block), 4 waves x 16 rows.  The backward is two kernels (dQ by query block, dK/dV by key block), so every
-// output row has one writer (no atomics, bitwise reproducible).
+// Same fragments and LDS images as above, but K/V (forward, dQ) or Q/dO (dK,dV) stream through LDS in 64-row tiles and the
+// softmax is computed online; nothing of size S x S exists anywhere.  The backward is two kernels (dQ by query block, dK/dV
+// by key block), so every output row has one writer (no atomics, bitwise reproducible).
+//   * a wave owns RB blocks of 16 rows: every K / V (Q / dO) fragment read from LDS feeds RB MFMAs (with one block per wave the
+//     kernels were LDS-bandwidth bound at 10 % of the MFMA peak: 16 KiB of fragment reads per 16 MFMAs);
+//   * tiles arrive by LDS-DMA (global_load_lds, swizzle applied to the source address) into a double buffer: the loads of
+//     tile t+1 are in flight while tile t is consumed, one barrier per tile;
+//   * softmax in the exp2 domain with the scale folded into one fma per score; the rescale of the running output is skipped
+//     while no row maximum of the wave moves;
+//   * workgroup -> (sequence, head, block): all blocks of one (sequence, head) run back to back on ONE XCD (XCD = id % 8), so
+//     its K / V are fetched from HBM once and served from that XCD's L2 afterwards.
 // =============================================================================================
 #define ATT_TILE 64
+#define ATT_LOG2E 1.4426950408889634f
+#define ATT_LN2 0.6931471805599453f
 
-__device__ __forceinline__ void att_stage_tile(const bf16_t* __restrict__ src, int ld, char* img, int row0, int S) {
-    for (int idx = threadIdx.x; idx < ATT_TILE * 8; idx += 256) {
-        const int r = idx >> 3, c = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row0 + r < S) v = *reinterpret_cast<const uint4*>(src + (size_t)(row0 + r) * ld + c * 8);
-        *reinterpret_cast<uint4*>(img + att_off(r, c)) = v;
+__device__ __forceinline__ void att_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// 64 rows x 128 bytes of a head slice -> the swizzled image of att_off() by LDS-DMA.  The destination of a wave's DMA is
+// lane-linear (physical chunk p = 8 r + s of the tile), so the thread that fills slot s of row r fetches the logical chunk the
+// swizzle (an involution) keeps there.  Rows past the sequence are clamped to its last row: finite values that the callers
+// multiply by exactly-zero probabilities.  256 threads, two 16-byte pieces each.
+__device__ __forceinline__ void att_stage_dma(const bf16_t* __restrict__ src, int ld, char* img, int row0, int S) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int p = it * 256 + tid, r = p >> 3, sl = p & 7;
+        const int c = ((((sl >> 1) ^ (r >> 1)) & 3) << 1) | (sl & 1);
+        const int gr = min(row0 + r, S - 1);
+        att_glds16(src + (size_t)gr * ld + c * 8, img + (size_t)(it * 256 + (tid & ~63)) * 16);
     }
 }
 
@@ -422,80 +443,137 @@ __device__ __forceinline__ bf16x8 att_global_frag(const bf16_t* __restrict__ bas
     return *reinterpret_cast<const bf16x8*>(base + (size_t)r * ld + ks * 32 + (lane >> 4) * 8);
 }
 
-__global__ __launch_bounds__(256) void attn_long_fwd_kernel(const AttArgs a) {
-    __shared__ __attribute__((aligned(16))) char Ks[ATT_TILE * 128];
-    __shared__ __attribute__((aligned(16))) char Vs[ATT_TILE * 128];
-    __shared__ __attribute__((aligned(16))) float madd[ATT_TILE];
-    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+// 1-D grid of nbh * nblk workgroups -> ((sequence, head), block)
+__device__ __forceinline__ void att_block_map(int nbh, int nblk, int& bh, int& blk) {
+    const int L = blockIdx.x;
+    if ((nbh & 7) == 0) {
+        const int slot = L >> 3;
+        bh = (slot / nblk) * 8 + (L & 7);
+        blk = slot % nblk;
+    } else {
+        bh = L / nblk;
+        blk = L % nblk;
+    }
+}
+
+__device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int RB, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const AttArgs a) {
+    __shared__ __attribute__((aligned(16))) char KV[2][2][ATT_TILE * 128];
+    int bh, qb;
+    att_block_map(a.nbh, a.nblk, bh, qb);
+    const int b = bh / a.heads, h = bh % a.heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
-    const int q0 = blockIdx.y * ATT_TILE + wave * 16;
-    const bf16x8 qf0 = att_global_frag(base, a.ld, q0, 0, lane, a.S), qf1 = att_global_frag(base, a.ld, q0, 1, lane, a.S);
-    float m = ATT_NEG, l = 0.f;
-    f32x4 o[4];
+    const int q0 = qb * (64 * RB) + wave * (16 * RB);
+    bf16x8 qf[RB][2];
+    float m[RB], l[RB];
+    f32x4 o[RB][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < RB; ++rb) {
+        qf[rb][0] = att_global_frag(base, a.ld, q0 + rb * 16, 0, lane, a.S);
+        qf[rb][1] = att_global_frag(base, a.ld, q0 + rb * 16, 1, lane, a.S);
+        m[rb] = ATT_NEG; l[rb] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[rb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c2 = a.scale * ATT_LOG2E;
     const int ntiles = (a.S + ATT_TILE - 1) / ATT_TILE;
+    att_stage_dma(base + a.Hd, a.ld, KV[0][0], 0, a.S);
+    att_stage_dma(base + 2 * a.Hd, a.ld, KV[0][1], 0, a.S);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * ATT_TILE;
-        __syncthreads();
-        att_stage_tile(base + a.Hd, a.ld, Ks, k0, a.S);
-        att_stage_tile(base + 2 * a.Hd, a.ld, Vs, k0, a.S);
-        if (threadIdx.x < ATT_TILE) {
-            const int k = k0 + threadIdx.x;
-            madd[threadIdx.x] = (k < a.S && (!a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
+        __syncthreads();       // tile kt has landed (vmcnt(0) of every wave) and nobody still reads the other buffer
+        if (kt + 1 < ntiles) {
+            att_stage_dma(base + a.Hd, a.ld, KV[(kt + 1) & 1][0], k0 + ATT_TILE, a.S);
+            att_stage_dma(base + 2 * a.Hd, a.ld, KV[(kt + 1) & 1][1], k0 + ATT_TILE, a.S);
         }
-        __syncthreads();
-        f32x4 sc[4];
-        float tmax = ATT_NEG;
+        const char* Ks = KV[kt & 1][0];
+        const char* Vs = KV[kt & 1][1];
+        f32x4 sc[RB][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, 0, lane), qf0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, 1, lane), qf1, acc, 0, 0, 0);
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(madd + t * 16 + 4 * g);
+            const bf16x8 k0f = att_row_frag(Ks, t * 16, 0, lane), k1f = att_row_frag(Ks, t * 16, 1, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[r] = acc[r] * a.scale + mk[r];
-                tmax = fmaxf(tmax, acc[r]);
+            for (int rb = 0; rb < RB; ++rb) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0f, qf[rb][0], acc, 0, 0, 0);
+                sc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f, qf[rb][1], acc, 0, 0, 0);
             }
-            sc[t] = acc;
         }
-        const float mn = fmaxf(m, group4_max(tmax));
-        const float alpha = __expf(m - mn);
-        float ps = 0.f;
+        if (MASK || k0 + ATT_TILE > a.S) {      // (selects, no short-circuit: every mask load is issued before the first use)
+            bool ok[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sc[t][r] = __expf(sc[t][r] - mn);
-                ps += sc[t][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + t * 16 + 4 * g + r;
+                    ok[t][r] = key < a.S;
+                    if (MASK) ok[t][r] = ok[t][r] & (a.mask[(size_t)b * a.S + min(key, a.S - 1)] != 0);
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) sc[rb][t][r] = ok[t][r] ? sc[rb][t][r] : ATT_NEG;
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float tmax = ATT_NEG;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sc[rb][t][r]);
+            const float mn = fmaxf(m[rb], group4_max(tmax) * c2);
+            const float alpha = att_exp2(m[rb] - mn);
+            m[rb] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = att_exp2(fmaf(sc[rb][t][r], c2, -mn));
+                    sc[rb][t][r] = pv;
+                    ps += pv;
+                }
+            l[rb] = l[rb] * alpha + ps;     // partial over this lane group's keys; groups are summed at the end
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[rb][dt] *= alpha;
             }
-        l = l * alpha + ps;          // partial over this lane group's keys; groups are summed at the end
-        m = mn;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const bf16x8 pf = pack_frag(sc[2 * c], sc[2 * c + 1]);
+            bf16x8 pf[RB];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Vs, c * 32, dt, lane), pf, o[dt], 0, 0, 0);
+            for (int rb = 0; rb < RB; ++rb) pf[rb] = pack_frag(sc[rb][2 * c], sc[rb][2 * c + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vt = att_tr_frag(Vs, c * 32, dt, lane);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) o[rb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf[rb], o[rb][dt], 0, 0, 0);
+            }
         }
     }
-    l = group4_sum(l);
-    const float inv = 1.0f / l;
-    if (q0 + li < a.S) {
-        bf16_t* dst = a.ctx + ((size_t)b * a.S + q0 + li) * a.ldc + h * ATT_D + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 v;
-            v.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
-            v.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-            *reinterpret_cast<uint2*>(dst + dt * 16) = v;
+    for (int rb = 0; rb < RB; ++rb) {
+        const float lt = group4_sum(l[rb]);
+        const float inv = 1.0f / lt;
+        const int q = q0 + rb * 16 + li;
+        if (q < a.S) {
+            bf16_t* dst = a.ctx + ((size_t)b * a.S + q) * a.ldc + h * ATT_D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 v;
+                v.x = pack2bf(o[rb][dt][0] * inv, o[rb][dt][1] * inv);
+                v.y = pack2bf(o[rb][dt][2] * inv, o[rb][dt][3] * inv);
+                *reinterpret_cast<uint2*>(dst + dt * 16) = v;
+            }
+            if (g == 0 && a.lse) a.lse[((size_t)b * a.heads + h) * a.S + q] = (m[rb] + __log2f(lt)) * ATT_LN2;
         }
-        if (g == 0 && a.lse) a.lse[((size_t)b * a.heads + h) * a.S + q0 + li] = m + __logf(l);
     }
 }
 
@@ -513,140 +591,220 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void attn_long_dq_kernel(const AttArgs a, const float* __restrict__ delta) {
-    __shared__ __attribute__((aligned(16))) char Ks[ATT_TILE * 128];
-    __shared__ __attribute__((aligned(16))) char Vs[ATT_TILE * 128];
-    __shared__ __attribute__((aligned(16))) float madd[ATT_TILE];
-    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+// dQ of RB x 64 query rows per workgroup: K / V tiles stream through LDS; p = exp2(s c2 - lse log2e), dS = p (dP - delta) scale
+template <int RB, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const AttArgs a, const float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) char KV[2][2][ATT_TILE * 128];
+    int bh, qb;
+    att_block_map(a.nbh, a.nblk, bh, qb);
+    const int b = bh / a.heads, h = bh % a.heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
     const bf16_t* gbase = a.dctx + (size_t)b * a.S * a.lddc + h * ATT_D;
-    const int q0 = blockIdx.y * ATT_TILE + wave * 16;
-    const bf16x8 qf0 = att_global_frag(base, a.ld, q0, 0, lane, a.S), qf1 = att_global_frag(base, a.ld, q0, 1, lane, a.S);
-    const bf16x8 gf0 = att_global_frag(gbase, a.lddc, q0, 0, lane, a.S), gf1 = att_global_frag(gbase, a.lddc, q0, 1, lane, a.S);
-    const bool qok = q0 + li < a.S;
-    const size_t sidx = ((size_t)b * a.heads + h) * a.S + min(q0 + li, a.S - 1);
-    const float lq = qok ? a.lse[sidx] : 1.0e30f, dl = qok ? delta[sidx] : 0.f;
-    f32x4 dq[4];
+    const int q0 = qb * (64 * RB) + wave * (16 * RB);
+    bf16x8 qf[RB][2], gf[RB][2];
+    float lq2[RB], dl[RB];
+    f32x4 dq[RB][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r0 = q0 + rb * 16;
+        qf[rb][0] = att_global_frag(base, a.ld, r0, 0, lane, a.S);
+        qf[rb][1] = att_global_frag(base, a.ld, r0, 1, lane, a.S);
+        gf[rb][0] = att_global_frag(gbase, a.lddc, r0, 0, lane, a.S);
+        gf[rb][1] = att_global_frag(gbase, a.lddc, r0, 1, lane, a.S);
+        const bool qok = r0 + li < a.S;
+        const size_t sidx = ((size_t)b * a.heads + h) * a.S + min(r0 + li, a.S - 1);
+        lq2[rb] = qok ? a.lse[sidx] * ATT_LOG2E : 1.0e30f;
+        dl[rb] = qok ? delta[sidx] : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[rb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c2 = a.scale * ATT_LOG2E;
     const int ntiles = (a.S + ATT_TILE - 1) / ATT_TILE;
+    att_stage_dma(base + a.Hd, a.ld, KV[0][0], 0, a.S);
+    att_stage_dma(base + 2 * a.Hd, a.ld, KV[0][1], 0, a.S);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * ATT_TILE;
         __syncthreads();
-        att_stage_tile(base + a.Hd, a.ld, Ks, k0, a.S);
-        att_stage_tile(base + 2 * a.Hd, a.ld, Vs, k0, a.S);
-        if (threadIdx.x < ATT_TILE) {
-            const int k = k0 + threadIdx.x;
-            madd[threadIdx.x] = (k < a.S && (!a.mask || a.mask[(size_t)b * a.S + k] != 0)) ? 0.f : ATT_NEG;
+        if (kt + 1 < ntiles) {
+            att_stage_dma(base + a.Hd, a.ld, KV[(kt + 1) & 1][0], k0 + ATT_TILE, a.S);
+            att_stage_dma(base + 2 * a.Hd, a.ld, KV[(kt + 1) & 1][1], k0 + ATT_TILE, a.S);
         }
-        __syncthreads();
-        f32x4 ds[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, 0, lane), qf0, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, 1, lane), qf1, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Vs, t * 16, 0, lane), gf0, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Vs, t * 16, 1, lane), gf1, dp, 0, 0, 0);
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(madd + t * 16 + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[r] * a.scale + mk[r] - lq);
-                ds[t][r] = p * (dp[r] - dl) * a.scale;
-            }
-        }
+        const char* Ks = KV[kt & 1][0];
+        const char* Vs = KV[kt & 1][1];
+        const bool edge = MASK || k0 + ATT_TILE > a.S;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const bf16x8 dsf = pack_frag(ds[2 * c], ds[2 * c + 1]);
+            f32x4 ds[RB][2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Ks, c * 32, dt, lane), dsf, dq[dt], 0, 0, 0);
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int t = 2 * c + t2;
+                const bf16x8 k0f = att_row_frag(Ks, t * 16, 0, lane), k1f = att_row_frag(Ks, t * 16, 1, lane);
+                const bf16x8 v0f = att_row_frag(Vs, t * 16, 0, lane), v1f = att_row_frag(Vs, t * 16, 1, lane);
+                bool ok[4] = {true, true, true, true};
+                if (edge) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + t * 16 + 4 * g + r;
+                        ok[r] = key < a.S;
+                        if (MASK) ok[r] = ok[r] & (a.mask[(size_t)b * a.S + min(key, a.S - 1)] != 0);
+                    }
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0f, qf[rb][0], sv, 0, 0, 0);
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f, qf[rb][1], sv, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0f, gf[rb][0], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1f, gf[rb][1], dp, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = att_exp2(fmaf(sv[r], c2, -lq2[rb]));
+                        pv = ok[r] ? pv : 0.f;
+                        ds[rb][t2][r] = pv * (dp[r] - dl[rb]) * a.scale;
+                    }
+                }
+            }
+            bf16x8 dsf[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) dsf[rb] = pack_frag(ds[rb][0], ds[rb][1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kt_f = att_tr_frag(Ks, c * 32, dt, lane);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) dq[rb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[rb], dq[rb][dt], 0, 0, 0);
+            }
         }
     }
-    if (qok) {
-        bf16_t* dst = a.dqkv + ((size_t)b * a.S + q0 + li) * a.lddq + h * ATT_D + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 v;
-            v.x = pack2bf(dq[dt][0], dq[dt][1]);
-            v.y = pack2bf(dq[dt][2], dq[dt][3]);
-            *reinterpret_cast<uint2*>(dst + dt * 16) = v;
+    for (int rb = 0; rb < RB; ++rb) {
+        const int q = q0 + rb * 16 + li;
+        if (q < a.S) {
+            bf16_t* dst = a.dqkv + ((size_t)b * a.S + q) * a.lddq + h * ATT_D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 v;
+                v.x = pack2bf(dq[rb][dt][0], dq[rb][dt][1]);
+                v.y = pack2bf(dq[rb][dt][2], dq[rb][dt][3]);
+                *reinterpret_cast<uint2*>(dst + dt * 16) = v;
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void attn_long_dkv_kernel(const AttArgs a, const float* __restrict__ delta) {
-    __shared__ __attribute__((aligned(16))) char Qs[ATT_TILE * 128];
-    __shared__ __attribute__((aligned(16))) char Gs[ATT_TILE * 128];
-    __shared__ __attribute__((aligned(16))) float lses[ATT_TILE];
-    __shared__ __attribute__((aligned(16))) float dels[ATT_TILE];
-    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+// dK, dV of RB x 64 keys per workgroup: Q / dO tiles (+ their lse, delta) stream through LDS
+template <int RB, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_flash_dkv_kernel(const AttArgs a, const float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) char QG[2][2][ATT_TILE * 128];
+    __shared__ __attribute__((aligned(16))) float lses[2][ATT_TILE];
+    __shared__ __attribute__((aligned(16))) float dels[2][ATT_TILE];
+    int bh, kb;
+    att_block_map(a.nbh, a.nblk, bh, kb);
+    const int b = bh / a.heads, h = bh % a.heads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)b * a.S * a.ld + h * ATT_D;
     const bf16_t* gbase = a.dctx + (size_t)b * a.S * a.lddc + h * ATT_D;
-    const int k0 = blockIdx.y * ATT_TILE + wave * 16;
-    const bf16x8 kf0 = att_global_frag(base + a.Hd, a.ld, k0, 0, lane, a.S), kf1 = att_global_frag(base + a.Hd, a.ld, k0, 1, lane, a.S);
-    const bf16x8 vf0 = att_global_frag(base + 2 * a.Hd, a.ld, k0, 0, lane, a.S), vf1 = att_global_frag(base + 2 * a.Hd, a.ld, k0, 1, lane, a.S);
-    const int key = k0 + li;
-    const float mk = (key < a.S && (!a.mask || a.mask[(size_t)b * a.S + key] != 0)) ? 0.f : ATT_NEG;
-    f32x4 dk[4], dv[4];
+    const size_t srow = ((size_t)b * a.heads + h) * a.S;
+    const int kbase = kb * (64 * RB) + wave * (16 * RB);
+    bf16x8 kf[RB][2], vf[RB][2];
+    bool kok[RB];
+    f32x4 dk[RB][4], dv[RB][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r0 = kbase + rb * 16;
+        kf[rb][0] = att_global_frag(base + a.Hd, a.ld, r0, 0, lane, a.S);
+        kf[rb][1] = att_global_frag(base + a.Hd, a.ld, r0, 1, lane, a.S);
+        vf[rb][0] = att_global_frag(base + 2 * a.Hd, a.ld, r0, 0, lane, a.S);
+        vf[rb][1] = att_global_frag(base + 2 * a.Hd, a.ld, r0, 1, lane, a.S);
+        const int key = r0 + li;
+        kok[rb] = key < a.S;
+        if (MASK) kok[rb] = kok[rb] & (a.mask[(size_t)b * a.S + min(key, a.S - 1)] != 0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[rb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[rb][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const float c2 = a.scale * ATT_LOG2E;
     const int ntiles = (a.S + ATT_TILE - 1) / ATT_TILE;
+    att_stage_dma(base, a.ld, QG[0][0], 0, a.S);
+    att_stage_dma(gbase, a.lddc, QG[0][1], 0, a.S);
+    if (threadIdx.x < ATT_TILE) {
+        const int q = threadIdx.x;
+        lses[0][q] = q < a.S ? a.lse[srow + min(q, a.S - 1)] * ATT_LOG2E : 1.0e30f;
+        dels[0][q] = q < a.S ? delta[srow + min(q, a.S - 1)] : 0.f;
+    }
     for (int qt = 0; qt < ntiles; ++qt) {
-        const int q0 = qt * ATT_TILE;
+        const int qn = (qt + 1) * ATT_TILE;
         __syncthreads();
-        att_stage_tile(base, a.ld, Qs, q0, a.S);
-        att_stage_tile(gbase, a.lddc, Gs, q0, a.S);
-        if (threadIdx.x < ATT_TILE) {
-            const int q = q0 + threadIdx.x;
-            const size_t si = ((size_t)b * a.heads + h) * a.S + min(q, a.S - 1);
-            lses[threadIdx.x] = q < a.S ? a.lse[si] : 1.0e30f;
-            dels[threadIdx.x] = q < a.S ? delta[si] : 0.f;
+        float nl = 1.0e30f, nd = 0.f;
+        if (qt + 1 < ntiles) {
+            att_stage_dma(base, a.ld, QG[(qt + 1) & 1][0], qn, a.S);
+            att_stage_dma(gbase, a.lddc, QG[(qt + 1) & 1][1], qn, a.S);
+            if (threadIdx.x < ATT_TILE) {
+                const int q = qn + threadIdx.x;
+                if (q < a.S) { nl = a.lse[srow + q] * ATT_LOG2E; nd = delta[srow + q]; }
+            }
         }
-        __syncthreads();
+        const char* Qs = QG[qt & 1][0];
+        const char* Gs = QG[qt & 1][1];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            f32x4 pp[2], ds[2];
+            f32x4 pp[RB][2], ds[RB][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ql = c * 32 + t * 16;
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Qs, ql, 0, lane), kf0, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Qs, ql, 1, lane), kf1, s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Gs, ql, 0, lane), vf0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Gs, ql, 1, lane), vf1, dp, 0, 0, 0);
-                const f32x4 lq = *reinterpret_cast<const f32x4*>(lses + ql + 4 * g);
-                const f32x4 dl = *reinterpret_cast<const f32x4*>(dels + ql + 4 * g);
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int ql = c * 32 + t2 * 16;
+                const bf16x8 q0f = att_row_frag(Qs, ql, 0, lane), q1f = att_row_frag(Qs, ql, 1, lane);
+                const bf16x8 g0f = att_row_frag(Gs, ql, 0, lane), g1f = att_row_frag(Gs, ql, 1, lane);
+                const f32x4 lq = *reinterpret_cast<const f32x4*>(&lses[qt & 1][ql + 4 * g]);
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(&dels[qt & 1][ql + 4 * g]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(s[r] * a.scale + mk - lq[r]);
-                    pp[t][r] = p;
-                    ds[t][r] = p * (dp[r] - dl[r]) * a.scale;
+                for (int rb = 0; rb < RB; ++rb) {
+                    f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[rb][0], sv, 0, 0, 0);
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[rb][1], sv, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g0f, vf[rb][0], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g1f, vf[rb][1], dp, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = kok[rb] ? att_exp2(fmaf(sv[r], c2, -lq[r])) : 0.f;
+                        pp[rb][t2][r] = pv;
+                        ds[rb][t2][r] = pv * (dp[r] - dl[r]) * a.scale;
+                    }
                 }
             }
-            const bf16x8 pf = pack_frag(pp[0], pp[1]), dsf = pack_frag(ds[0], ds[1]);
+            bf16x8 pf[RB], dsf[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) { pf[rb] = pack_frag(pp[rb][0], pp[rb][1]); dsf[rb] = pack_frag(ds[rb][0], ds[rb][1]); }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Gs, c * 32, dt, lane), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Qs, c * 32, dt, lane), dsf, dk[dt], 0, 0, 0);
+                const bf16x8 gt = att_tr_frag(Gs, c * 32, dt, lane), qt_f = att_tr_frag(Qs, c * 32, dt, lane);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    dv[rb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf[rb], dv[rb][dt], 0, 0, 0);
+                    dk[rb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf[rb], dk[rb][dt], 0, 0, 0);
+                }
             }
         }
+        if (qt + 1 < ntiles && threadIdx.x < ATT_TILE) {     // buffer (qt+1)&1 was last read in iteration qt-1
+            lses[(qt + 1) & 1][threadIdx.x] = nl;
+            dels[(qt + 1) & 1][threadIdx.x] = nd;
+        }
     }
-    if (key < a.S) {
-        bf16_t* dst = a.dqkv + ((size_t)b * a.S + key) * a.lddq + h * ATT_D + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 v;
-            v.x = pack2bf(dk[dt][0], dk[dt][1]);
-            v.y = pack2bf(dk[dt][2], dk[dt][3]);
-            *reinterpret_cast<uint2*>(dst + a.Hd + dt * 16) = v;
-            v.x = pack2bf(dv[dt][0], dv[dt][1]);
-            v.y = pack2bf(dv[dt][2], dv[dt][3]);
-            *reinterpret_cast<uint2*>(dst + 2 * a.Hd + dt * 16) = v;
+    for (int rb = 0; rb < RB; ++rb) {
+        const int key = kbase + rb * 16 + li;
+        if (key < a.S) {
+            bf16_t* dst = a.dqkv + ((size_t)b * a.S + key) * a.lddq + h * ATT_D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 v;
+                v.x = pack2bf(dk[rb][dt][0], dk[rb][dt][1]);
+                v.y = pack2bf(dk[rb][dt][2], dk[rb][dt][3]);
+                *reinterpret_cast<uint2*>(dst + a.Hd + dt * 16) = v;
+                v.x = pack2bf(dv[rb][dt][0], dv[rb][dt][1]);
+                v.y = pack2bf(dv[rb][dt][2], dv[rb][dt][3]);
+                *reinterpret_cast<uint2*>(dst + 2 * a.Hd + dt * 16) = v;
+            }
         }
     }
 }
@@ -659,7 +817,19 @@ MMG_API int mmg_attention_long_fwd(const void* qkv, int ld, const long long* mas
     AttArgs a = {};
     a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = lse;
     a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
-    hipLaunchKernelGGL(attn_long_fwd_kernel, dim3(B * heads, cdiv(S, ATT_TILE)), dim3(256), 0, stream, a);
+    // 64 rows per wave (4 row blocks) once there are enough query blocks to fill the GPU twice over, else 32 / 16
+    const int rb_env = getenv("MMG_ATT_RB") ? atoi(getenv("MMG_ATT_RB")) : 0;      // (read per call: the tests walk through 1 / 2 / 4)
+    const long bhn = (long)B * heads;
+    const int rb = rb_env ? rb_env : (bhn * cdiv(S, 256) >= 1024 ? 4 : bhn * cdiv(S, 128) >= 1024 ? 2 : 1);
+    a.nbh = (int)bhn; a.nblk = cdiv(S, 64 * rb);
+    const dim3 grid((unsigned)(bhn * a.nblk));
+#define ATT_FWD(RBV)                                                                                         \
+    do {                                                                                                     \
+        if (mask) hipLaunchKernelGGL((attn_flash_fwd_kernel<RBV, true>), grid, dim3(256), 0, stream, a);     \
+        else hipLaunchKernelGGL((attn_flash_fwd_kernel<RBV, false>), grid, dim3(256), 0, stream, a);         \
+    } while (0)
+    if (rb == 4) ATT_FWD(4); else if (rb == 2) ATT_FWD(2); else ATT_FWD(1);
+#undef ATT_FWD
     MMG_LAUNCH_CHECK("mmg_attention_long_fwd");
     return 0;
 }
@@ -679,9 +849,23 @@ MMG_API int mmg_attention_long_bwd(const void* qkv, int ld, const long long* mas
     int blocks = (int)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
     hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)ctx, ldc, (const bf16_t*)dctx, lddc,
                        delta_ws, B, S, heads);
-    const dim3 grid(B * heads, cdiv(S, ATT_TILE));
-    hipLaunchKernelGGL(attn_long_dq_kernel, grid, dim3(256), 0, stream, a, (const float*)delta_ws);
-    hipLaunchKernelGGL(attn_long_dkv_kernel, grid, dim3(256), 0, stream, a, (const float*)delta_ws);
+    const int rbq_env = getenv("MMG_ATT_RB") ? atoi(getenv("MMG_ATT_RB")) : 0;
+    const int rbk_env = getenv("MMG_ATT_RB_DKV") ? atoi(getenv("MMG_ATT_RB_DKV")) : (rbq_env > 2 ? 2 : rbq_env);
+    const long bhn = (long)B * heads;
+    const int rbq = rbq_env ? rbq_env : (bhn * cdiv(S, 256) >= 1024 ? 4 : bhn * cdiv(S, 128) >= 1024 ? 2 : 1);
+    const int rbk = rbk_env ? rbk_env : (bhn * cdiv(S, 128) >= 1024 ? 2 : 1);
+    const float* dws = (const float*)delta_ws;
+    a.nbh = (int)bhn;
+#define ATT_BWD(KERNEL, RBV)                                                                                   \
+    do {                                                                                                       \
+        a.nblk = cdiv(S, 64 * RBV);                                                                            \
+        const dim3 grid((unsigned)(bhn * a.nblk));                                                             \
+        if (mask) hipLaunchKernelGGL((KERNEL<RBV, true>), grid, dim3(256), 0, stream, a, dws);                 \
+        else hipLaunchKernelGGL((KERNEL<RBV, false>), grid, dim3(256), 0, stream, a, dws);                     \
+    } while (0)
+    if (rbq == 4) ATT_BWD(attn_flash_dq_kernel, 4); else if (rbq == 2) ATT_BWD(attn_flash_dq_kernel, 2); else ATT_BWD(attn_flash_dq_kernel, 1);
+    if (rbk == 2) ATT_BWD(attn_flash_dkv_kernel, 2); else ATT_BWD(attn_flash_dkv_kernel, 1);
+#undef ATT_BWD
     MMG_LAUNCH_CHECK("mmg_attention_long_bwd");
     return 0;
 }
