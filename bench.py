@@ -48,7 +48,7 @@ def build(args, comm):
     cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf", [
         f"networks={net}", f"tokenizer=bert_clinical_seqlen={args.seq_len}", "networks/dropout=dropout0",
         f"networks.image_encoder.micro_batch={args.micro_batch}", f"networks.image_encoder.image_size={args.image_size}",
-        "optimizer.config.fused=true"] + (["networks.image_encoder.checkpoint=true"] if args.checkpoint and args.variant != "vit_b16" else [])
+        "optimizer.config.fused=true"] + (["networks.image_encoder.checkpoint=true"] if args.checkpoint else [])
         + (["networks.image_encoder.fp8=true"] if args.fp8 and args.variant != "vit_b16" else []))
     seeding(cfg.base.seed)
     model = MMGCLIP(cfg)

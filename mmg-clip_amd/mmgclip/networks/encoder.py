@@ -109,8 +109,9 @@ class ViTB16Encoder(ViTTower):
     """ViT-B/16 on raw pixels (BASELINE config C4; torchvision `vit_b_16` state-dict layout, class-token pooling)."""
 
     def __init__(self, pretrained=None, image_features_dimension=None, in_chans=1, scale16=True, micro_batch=256, freeze=False,
-                 image_size=224, layers=12):
-        super().__init__(image_size=image_size, in_chans=in_chans, layers=layers, scale16=scale16, micro_batch=micro_batch)
+                 image_size=224, layers=12, checkpoint=False):
+        super().__init__(image_size=image_size, in_chans=in_chans, layers=layers, scale16=scale16, micro_batch=micro_batch,
+                         checkpoint=checkpoint)
         if isinstance(pretrained, str) and os.path.isfile(pretrained):
             sd = _load_state_file(pretrained)
             self.model.load_state_dict({k: v for k, v in sd.items() if not k.startswith("heads.")}, strict=True)

@@ -51,8 +51,9 @@ class MMGCLIP(nn.Module):
                 pretrained=_get(ie, "pretrained_path"), image_features_dimension=ie.image_features_dimension,
                 in_chans=_get(ie, "in_chans", 1), scale16=_get(ie, "scale16", True), micro_batch=_get(ie, "micro_batch", 64),
                 freeze=_get(ie, "freeze", False),
+                checkpoint=_get(ie, "checkpoint", False),
                 **({"image_size": _get(ie, "image_size", 224)} if enc_name == "ViTB16Encoder" else
-                   {"checkpoint": _get(ie, "checkpoint", False), "fp8": _get(ie, "fp8", False)})).to(self.device)
+                   {"fp8": _get(ie, "fp8", False)})).to(self.device)
             logger.info(f"Using {self.image_encoder.__class__.__name__}")
 
         te = self.config.networks.text_encoder

@@ -56,8 +56,9 @@ class ViTTower(nn.Module):
     """pixels fp32 [n, Cin, H, W] -> class-token features [n, hidden]."""
 
     def __init__(self, image_size=224, in_chans=1, hidden=768, layers=12, heads=12, mlp_dim=3072, patch=16, scale16=True,
-                 micro_batch=256):
+                 micro_batch=256, checkpoint=False):
         super().__init__()
+        self.checkpoint = checkpoint        # keep only each micro-batch's pixels, re-run its forward inside its backward
         assert hidden == 64 * heads, "the attention kernel is specialised for head_dim 64"
         self.image_size, self.in_chans, self.hidden, self.layers, self.heads = image_size, in_chans, hidden, layers, heads
         self.mlp_dim, self.patch, self.scale16, self.micro_batch = mlp_dim, patch, scale16, micro_batch
@@ -194,11 +195,12 @@ class _ViTFn(torch.autograd.Function):
     def forward(ctx, tower, images, anchor):
         tower._refresh_working_copies()
         save = anchor is not None
+        ckpt = save and tower.checkpoint
         feats, saved = [], []
         for i in range(0, images.shape[0], tower.micro_batch):
-            ft, sv = tower._forward_mb(images[i:i + tower.micro_batch], save)
+            ft, sv = tower._forward_mb(images[i:i + tower.micro_batch], save and not ckpt)
             feats.append(ft)
-            saved.append(sv)
+            saved.append({"recompute": images[i:i + tower.micro_batch], "B": ft.shape[0]} if ckpt else sv)
         ctx.tower, ctx.saved_mb = tower, saved if save else None
         return torch.cat(feats, 0) if len(feats) > 1 else feats[0]
 
@@ -209,6 +211,8 @@ class _ViTFn(torch.autograd.Function):
         dfeat = dfeat.float().contiguous()
         i = 0
         for sv in ctx.saved_mb:
+            if "recompute" in sv:
+                _, sv = tower._forward_mb(sv["recompute"], True)
             tower._backward_mb(dfeat[i:i + sv["B"]].contiguous(), sv)
             i += sv["B"]
         ctx.saved_mb = None

@@ -200,6 +200,28 @@ def test_vit_tower_forward_backward(dev):
     assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
 
 
+def test_vit_gradient_checkpointing_equals_plain_backward(dev):
+    """checkpoint=True keeps only the pixels of a micro-batch and re-runs its forward in the backward: same features and
+    (deterministic kernels, one writer per row) the same gradients as the saving path."""
+    from mmgclip.networks.encoder import ViTB16Encoder
+    img = torch.rand(4, 1, 96, 96, generator=torch.Generator().manual_seed(1)).to(dev)
+    wgt = torch.randn(4, 768, generator=torch.Generator().manual_seed(2)).to(dev)
+    ref = ViTB16Encoder(image_size=96, layers=2, micro_batch=2)
+    _randomize(ref, 3)
+    out = {}
+    for ck in (False, True):
+        tower = ViTB16Encoder(image_size=96, layers=2, micro_batch=2, checkpoint=ck)
+        tower.load_state_dict(ref.state_dict())
+        tower = tower.to(dev)
+        feat = tower(img)
+        (feat * wgt).sum().backward()
+        out[ck] = (feat.detach().clone(), {n: p.grad.detach().clone() for n, p in tower.model.named_parameters()})
+    assert torch.equal(out[True][0], out[False][0])
+    for n, gr in out[False][1].items():
+        rel = float((out[True][1][n] - gr).norm() / (gr.norm() + 1e-30))
+        assert rel < 1e-5, (n, rel)          # weight-gradient GEMMs accumulate with fp32 atomics: order noise only
+
+
 def test_vit_tower_long_sequence_path(dev):
     """S = (272/16)^2 + 1 = 290 > 256 tokens: the tiled attention kernels carry the forward and the backward."""
     from mmgclip.networks.encoder import ViTB16Encoder
