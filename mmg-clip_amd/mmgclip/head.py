@@ -54,7 +54,7 @@ def rows_forward(x_loc, y_all, scale, diag_off=0, want_logits=False):
 class ScaledLogits(torch.autograd.Function):
     """logits_per_image, logits_per_text = s * I @ T.t(), s * T @ I.t()  (mmgclip_model.py:135-136).
 
-    Materialises both [n,n] matrices because the reference API returns them; the backward takes arbitrary
+    Materialises both matrices ([n,k] and [k,n]; k = n in training) because the reference API returns them; the backward takes arbitrary
     upstream gradients of both (mmg_clip_rows_bwd_dense).
     """
 
@@ -72,15 +72,16 @@ class ScaledLogits(torch.autograd.Function):
     def backward(ctx, dli, dlt):
         img, txt, scale = ctx.saved_tensors
         n, D = img.shape
+        k = txt.shape[0]                  # k != n for zero-shot prompt scoring (PromptClassifier): Li [n,k], Lt [k,n]
         dli = _f32c(dli) if dli is not None else None
         dlt = _f32c(dlt) if dlt is not None else None
         dimg = torch.empty_like(img)
         dtxt = torch.empty_like(txt)
         dscale = torch.zeros(1, device=img.device, dtype=torch.float32)
         # d img = s (dLi + dLt^T) T ; d txt = s (dLt + dLi^T) I ; ds counted once (first call)
-        call("mmg_clip_rows_bwd_dense", ptr(img), ptr(txt), ptr(scale), ptr(dli), n, ptr(dlt), n, n, n, D,
+        call("mmg_clip_rows_bwd_dense", ptr(img), ptr(txt), ptr(scale), ptr(dli), k, ptr(dlt), n, n, k, D,
              ptr(dimg), ptr(dscale), stream())
-        call("mmg_clip_rows_bwd_dense", ptr(txt), ptr(img), ptr(scale), ptr(dlt), n, ptr(dli), n, n, n, D,
+        call("mmg_clip_rows_bwd_dense", ptr(txt), ptr(img), ptr(scale), ptr(dlt), n, ptr(dli), k, k, n, D,
              ptr(dtxt), None, stream())
         return dimg, dtxt, dscale.reshape(())
 

@@ -148,3 +148,64 @@ class MMGCLIP(nn.Module):
             text_embeddings2 = self.text_projection_layer(text_features2)
             output['text_embeddings2'] = head.L2Normalize.apply(text_embeddings2)
         return output
+
+
+class PromptClassifier(nn.Module):
+    """Zero-shot classifier wrapper around an MMGCLIP model — drop-in for mmgclip/networks/mmgclip_model.py:168-257.
+
+    `forward(image_features, class_list, visualize, image_id, ground_truth)` tokenises the class prompts
+    (`padding="max_length"`, `max_length = config.tokenizer.config.sequence_length`), runs the model in eval mode without
+    gradients and returns `classes_similarities = softmax(logits_per_image)` [n, k], `similarities_argmax` (of the first
+    image, like the reference) and `class_list`.  `tokenizer` (additive argument): a callable with the HF tokenizer call
+    signature; by default `AutoTokenizer.from_pretrained(config.tokenizer.config.tokenizer_name)` as in the reference
+    (`:185`), and - only where that vocabulary cannot be loaded (offline box) - the hashed stand-in ids of
+    `dataset/synthetic.py`, with a warning.  The bar plot (`:212-255`) is drawn when matplotlib is importable.
+    """
+
+    def __init__(self, model=None, tokenizer=None):
+        super().__init__()
+        self.model = model
+        self.device = model.device
+        self.tokenizer = tokenizer
+        if self.tokenizer is None:
+            name = self.model.config.tokenizer.config.tokenizer_name
+            try:
+                from transformers import AutoTokenizer
+                self.tokenizer = AutoTokenizer.from_pretrained(pretrained_model_name_or_path=name)
+            except Exception as e:      # no vocabulary on an offline machine
+                logger.warning(f"tokenizer `{name}` unavailable ({type(e).__name__}); using hashed stand-in token ids")
+
+    def _tokens(self, class_list):
+        S = self.model.config.tokenizer.config.sequence_length
+        if self.tokenizer is not None:
+            return self.tokenizer(class_list, padding="max_length", truncation=True, return_tensors="pt", max_length=S)
+        from ..dataset.synthetic import synthetic_prompt_tokens
+        vocab = self.model.text_encoder.model.embeddings.word_embeddings.weight.shape[0]
+        return synthetic_prompt_tokens(list(class_list), S, vocab_size=vocab)
+
+    def forward(self, image_features, class_list, visualize=True, image_id=None, ground_truth=None):
+        inputs = {"image_features": image_features, "text_tokens": self._tokens(class_list)}
+        self.model.eval()
+        with torch.no_grad():
+            classes_similarities = self.model(inputs)['logits_per_image']        # images are rows, prompts are columns
+            classes_similarities = classes_similarities.softmax(dim=-1)
+        outputs = {"classes_similarities": classes_similarities,
+                   "similarities_argmax": torch.argmax(classes_similarities, dim=-1)[0].item(),
+                   "class_list": class_list}
+        if visualize:
+            assert image_id is not None, "For visualizing results, image_id value is required."
+            try:
+                import matplotlib.pyplot as plt
+            except ImportError:
+                logger.warning("matplotlib is not installed: skipping the probability plot")
+                return outputs
+            probs = classes_similarities.detach().cpu().numpy().reshape(-1)[:len(class_list)]
+            y = np.arange(len(class_list))
+            plt.figure(figsize=(7, 6))
+            plt.barh(y, probs)
+            plt.gca().invert_yaxis()
+            plt.yticks(y, class_list)
+            plt.xlabel("probability")
+            plt.title(f"{image_id}" + (f"  TP: {ground_truth}" if ground_truth else ""))
+            plt.show()
+        return outputs

@@ -45,6 +45,27 @@ def test_dropin_tail_matches_reference_golden(golden_dir, dev, n):
     np.testing.assert_allclose(ls.grad.cpu().numpy(), g["clip_dlogit_scale"], rtol=GRAD_RTOL, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,k", [(3, 5), (40, 8), (1, 2)])
+def test_rectangular_logits_and_their_backward(dev, n, k):
+    """n images against k != n prompts (zero-shot scoring): both matrices and arbitrary upstream gradients vs torch autograd."""
+    from mmgclip import head
+    g = torch.Generator().manual_seed(n * 100 + k)
+    img = torch.nn.functional.normalize(torch.randn(n, 512, generator=g), dim=1)
+    txt = torch.nn.functional.normalize(torch.randn(k, 512, generator=g), dim=1)
+    wi, wt = torch.randn(n, k, generator=g), torch.randn(k, n, generator=g)
+    a, b, s = img.clone().requires_grad_(True), txt.clone().requires_grad_(True), torch.tensor(14.2857, requires_grad=True)
+    ((s * a @ b.t()) * wi).sum().add(((s * b @ a.t()) * wt).sum()).backward()
+    ad, bd, sd = img.to(dev).requires_grad_(True), txt.to(dev).requires_grad_(True), torch.tensor(14.2857, device=dev, requires_grad=True)
+    li, lt = head.ScaledLogits.apply(ad, bd, sd)
+    assert li.shape == (n, k) and lt.shape == (k, n)
+    np.testing.assert_allclose(li.detach().cpu().numpy(), (14.2857 * img @ txt.t()).numpy(), atol=LOGIT_ATOL)
+    np.testing.assert_allclose(lt.detach().cpu().numpy(), (14.2857 * txt @ img.t()).numpy(), atol=LOGIT_ATOL)
+    ((li * wi.to(dev)).sum() + (lt * wt.to(dev)).sum()).backward()
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(sd.grad.cpu().numpy(), s.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("n", [8, 32, 37, 256])
 def test_fused_loss_matches_reference_golden(golden_dir, dev, n):
     """The no-materialisation path gives the same loss and gradients as the reference's CLIPLoss."""

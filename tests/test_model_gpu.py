@@ -154,3 +154,30 @@ def test_resnet50_image_encoder_config(dev, monkeypatch):
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert torch.equal(w_frozen, model.image_encoder.model.layer1[0].conv1.weight.detach())
+
+
+def test_prompt_classifier_zero_shot_scores(dev, monkeypatch):
+    """PromptClassifier (reference mmgclip_model.py:168-210): softmax over the prompt axis of logits_per_image for n images
+    against k != n class prompts, vs the oracle on the same weights and tokens."""
+    from mmgclip.dataset.synthetic import synthetic_batch, synthetic_prompt_tokens
+    from mmgclip.networks.mmgclip_model import MMGCLIP, PromptClassifier
+    _small_bert(monkeypatch)
+    torch.manual_seed(0)
+    model = MMGCLIP(_cfg("networks.text_encoder.random_init=true", "tokenizer=bert_clinical_seqlen=77"))
+    classes = ["Finding suggesting benign.", "Finding suggesting malignant.", "Mass shape is oval.", "Mass shape is irregular.",
+               "BIRADS score of 4."]
+    feats = synthetic_batch(3, S=77, vocab_size=3000, seed=5)["image_features"]
+    clf = PromptClassifier(model, tokenizer=lambda strings, **kw: synthetic_prompt_tokens(strings, kw["max_length"], vocab_size=3000))
+    out = clf(feats, classes, visualize=False)
+    assert set(out) == {"classes_similarities", "similarities_argmax", "class_list"} and out["class_list"] is classes
+    probs = out["classes_similarities"]
+    assert probs.shape == (3, 5) and not probs.requires_grad and not model.training
+    ref = _oracle_outputs(model, {"image_features": feats, "text_tokens": synthetic_prompt_tokens(classes, 77, vocab_size=3000)},
+                          pixels=False)["logits_per_image"].softmax(-1)
+    np.testing.assert_allclose(probs.cpu().numpy(), ref.numpy(), atol=2e-2)
+    assert out["similarities_argmax"] == int(ref[0].argmax())
+    with pytest.raises(AssertionError, match="image_id"):
+        clf(feats, classes)                                   # visualize defaults to True and needs an image id, like the reference
+    # default construction on an offline box: hashed stand-in ids, same call path
+    out2 = PromptClassifier(model)(feats[:1], classes[:2], visualize=False)
+    assert out2["classes_similarities"].shape == (1, 2)
