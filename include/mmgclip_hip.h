@@ -206,6 +206,21 @@ int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const
                         void* dxln, float* mean, float* rstd, float* ln_dw, float* ln_db, long long M, int C,
                         mmg_stream_t stream);
 
+/* ---- AveragedMedicalCLIPLoss helpers (reference mmgclip/loss/losses.py:98-216) ------------------------------------------------ */
+
+/* `_assign_labels` (losses.py:148-162) on the device: walking i = 0..n-1, an unlabelled text opens the next cluster and every
+ * still unlabelled j > i with sim[i][j] >= threshold joins it.  sim fp32 [n,n] (ld); labels int64 [n]; counts int32 [n]
+ * (members per cluster, first *k_out entries valid); k_out int32 device scalar = number of clusters.  n <= 16384. */
+int mmg_greedy_threshold_labels(const float* sim, int ld, int n, float threshold, long long* labels, int* counts, int* k_out,
+                                mmg_stream_t stream);
+
+/* `_average_logits` (losses.py:164-186): out[i,c] = mean_{j: labels[j]==c} logits[i,j]  (logits fp32 [n,N], out fp32 [n,k]),
+ * and its backward dlogits[i,j] = dout[i,labels[j]] / counts[labels[j]]. */
+int mmg_cluster_mean_cols_fwd(const float* logits, int ld, int n, int N, const long long* labels, const int* counts, int k,
+                              float* out, int ldo, mmg_stream_t stream);
+int mmg_cluster_mean_cols_bwd(const float* dout, int ldo, int n, int N, const long long* labels, const int* counts,
+                              float* dlogits, int ld, mmg_stream_t stream);
+
 /* ---- fp8 (OCP e4m3) forward GEMM path: BASELINE config C5 "ConvNeXt-base fp8 MFMA path" ---------------------------------
  * The reference has no reduced-precision path (its towers run torch fp32, mmgclip/networks/encoder.py:53,156); these replace
  * the same nn.Linear forwards of torchvision's CNBlock as mmg_gemm_nt_bf16 does, on v_mfma_f32_16x16x128_f8f6f4 (twice the

@@ -198,3 +198,38 @@ class FusedClipLoss(torch.autograd.Function):
 def fused_clip_loss(image_embeddings, text_embeddings, logit_scale, comm=None, _backend=None):
     """CLIPLoss on normalised embeddings; `logit_scale` is the already exponentiated scale (a tensor)."""
     return FusedClipLoss.apply(image_embeddings, text_embeddings, logit_scale, comm, _backend)
+
+
+def greedy_threshold_labels(sim, threshold):
+    """losses.py:148-162 on the device: (labels int64 [n], counts int32 [n], k) — one 4-byte read-back for k."""
+    sim = _f32c(sim.detach())
+    n = sim.shape[0]
+    labels = torch.empty(n, device=sim.device, dtype=torch.int64)
+    counts = torch.empty(n, device=sim.device, dtype=torch.int32)
+    k = torch.empty(1, device=sim.device, dtype=torch.int32)
+    call("mmg_greedy_threshold_labels", ptr(sim), sim.stride(0), n, float(threshold), ptr(labels), ptr(counts), ptr(k), stream())
+    return labels, counts, int(k.item())
+
+
+class ClusterMeanCols(torch.autograd.Function):
+    """[n,N] logits -> [n,k] per-cluster column means (losses.py:164-186) and the matching gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, counts, k):
+        _hip.require_gpu(logits, labels, counts)
+        logits = _f32c(logits)
+        n, N = logits.shape
+        out = torch.empty(n, k, device=logits.device, dtype=torch.float32)
+        call("mmg_cluster_mean_cols_fwd", ptr(logits), logits.stride(0), n, N, ptr(labels), ptr(counts), k, ptr(out), k, stream())
+        ctx.save_for_backward(labels, counts)
+        ctx.shape = (n, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        labels, counts = ctx.saved_tensors
+        n, N = ctx.shape
+        dout = _f32c(dout)
+        dl = torch.empty(n, N, device=dout.device, dtype=torch.float32)
+        call("mmg_cluster_mean_cols_bwd", ptr(dout), dout.stride(0), n, N, ptr(labels), ptr(counts), ptr(dl), N, stream())
+        return dl, None, None, None

@@ -49,8 +49,11 @@ class MMGCLIPLoss(nn.Module):
 class AveragedMedicalCLIPLoss(nn.Module):
     """Text-similarity label clustering + column-averaged logits — losses.py:98-216.
 
-    The O(n^2) greedy clustering is host code in the reference too (losses.py:148-162) and stays on the host
-    (not a kernel target); similarities, logits and both cross-entropies run on the device kernels.
+    Everything runs on the device: similarities (fp32 MFMA head kernel), the greedy threshold clustering
+    (`mmg_greedy_threshold_labels`: the reference's Python double loop with one device read per element, losses.py:148-162,
+    as one kernel; the only host traffic is the 4-byte cluster count), the per-cluster column means and both cross-entropies.
+    `_assign_labels` / `_average_logits` keep the reference's signatures (a list of labels in and out) for callers that use
+    the helpers directly.
     """
 
     def __init__(self, similarity_threshold=0.65):
@@ -64,32 +67,19 @@ class AveragedMedicalCLIPLoss(nn.Module):
         return sim
 
     def _assign_labels(self, cosine_sim_matrix, threshold=0.65):
-        sim = cosine_sim_matrix.detach().cpu().tolist()
-        n = len(sim)
-        labels, cur = [-1] * n, 0
-        for i in range(n):
-            if labels[i] != -1:
-                continue
-            labels[i] = cur
-            row = sim[i]
-            for j in range(i + 1, n):
-                if labels[j] == -1 and row[j] >= threshold:
-                    labels[j] = cur
-            cur += 1
-        return labels
+        labels, _, _ = head.greedy_threshold_labels(cosine_sim_matrix, threshold)
+        return labels.tolist()
 
     def _average_logits(self, logits, list_labels):
-        cols = []
-        for label in sorted(set(list_labels)):
-            idx = torch.tensor([i for i, l in enumerate(list_labels) if l == label], device=logits.device)
-            cols.append(logits.index_select(1, idx).mean(dim=1))
-        return torch.stack(cols, dim=1)
+        labels = torch.as_tensor(list_labels, device=logits.device, dtype=torch.int64)
+        k = int(labels.max().item()) + 1
+        counts = torch.bincount(labels, minlength=logits.shape[1]).to(torch.int32)
+        return head.ClusterMeanCols.apply(logits, labels, counts, k)
 
     def forward(self, image_embeddings, text_embeddings, logit_scale, logits_per_image, logits_per_text, **kwargs):
         sim = self._mesaure_embeddings_similarity(text_embeddings)
-        list_labels = self._assign_labels(sim, threshold=self.similarity_threshold)
-        averaged = self._average_logits(logits=logits_per_image, list_labels=list_labels)
-        labels = torch.tensor(list_labels, device=averaged.device)
+        labels, counts, k = head.greedy_threshold_labels(sim, self.similarity_threshold)
+        averaged = head.ClusterMeanCols.apply(logits_per_image, labels, counts, k)
         loss_i = head.cross_entropy(averaged, labels)
         loss_t = head.cross_entropy(logits_per_text, labels)      # as the reference: [n,n] logits vs cluster ids
         return (loss_i + loss_t) / 2, labels

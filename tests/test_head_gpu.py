@@ -158,3 +158,29 @@ def test_cross_entropy_with_labels_matches_torch(dev):
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-6
     np.testing.assert_allclose(z.grad.cpu().numpy(), zc.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,groups,noise", [(8, 2, 0.0), (37, 5, 0.05), (256, 12, 0.2), (1500, 40, 0.3), (64, 64, 0.0)])
+def test_device_threshold_clustering_and_cluster_means(dev, n, groups, noise):
+    """`_assign_labels` / `_average_logits` of AveragedMedicalCLIPLoss (reference losses.py:148-186) on the device against the
+    oracle's restatement of the reference loops: identical labels (order-dependent greedy first fit), means and gradients."""
+    from mmgclip import head
+    from oracle import clip_oracle as O
+    g = torch.Generator().manual_seed(n)
+    centers = torch.nn.functional.normalize(torch.randn(groups, 64, generator=g), dim=1)
+    member = torch.randint(0, groups, (n,), generator=g)
+    txt = torch.nn.functional.normalize(centers[member] + noise * torch.randn(n, 64, generator=g), dim=1)
+    sim = txt @ txt.t()                       # noise makes the relation non-transitive: the visiting order matters
+    want = O.assign_labels(sim, 0.65)
+    labels, counts, k = head.greedy_threshold_labels(sim.to(dev), 0.65)
+    assert labels.dtype == torch.int64 and labels.cpu().tolist() == want
+    assert k == max(want) + 1 and counts[:k].cpu().tolist() == np.bincount(want).tolist()
+    logits = torch.randn(19, n, generator=g)
+    w = torch.randn(19, k, generator=g)
+    lr = logits.clone().requires_grad_(True)
+    (O.average_logits(lr, want) * w).sum().backward()
+    ld = logits.to(dev).requires_grad_(True)
+    out = head.ClusterMeanCols.apply(ld, labels, counts, k)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), O.average_logits(logits, want).numpy(), rtol=1e-5, atol=1e-6)
+    (out * w.to(dev)).sum().backward()
+    np.testing.assert_allclose(ld.grad.cpu().numpy(), lr.grad.numpy(), rtol=1e-5, atol=1e-7)
