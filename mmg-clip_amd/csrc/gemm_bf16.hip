@@ -424,7 +424,13 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     // 256x256 tile (8 waves, one workgroup per CU): 128 FLOP per operand byte pulled from L2, which is what bounds the
     // 128-wide tiles (~10 TB/s of L2->LDS traffic); used from this K upwards when N is a multiple of 256 (0 = never)
     static const int use_256 = getenv("MMG_GEMM_256") ? atoi(getenv("MMG_GEMM_256")) : 384;
-    if (use_256 && k64 && N % 256 == 0 && M >= 4096 && K >= use_256) launch_nt<256, 256, 64, 4, 2>(g, stream);
+    // one workgroup per CU for the 256-row tiles: a grid that fills the last round of 256 CUs badly (BERT's ~10 k packed
+    // tokens x N = 768: 123 tiles = 48 % of one round) goes to the next smaller tile when that one fills better
+    static const int fill_rule = getenv("MMG_GEMM_FILL") ? atoi(getenv("MMG_GEMM_FILL")) : 1;
+    auto fill = [](long wgs) { return (double)wgs / (double)(cdiv(wgs, 256) * 256L); };
+    const double f256 = fill((long)cdiv(M, 256) * cdiv(N, 256)), f128 = fill((long)cdiv(M, 256) * cdiv(N, 128));
+    const bool fills = !fill_rule || f256 >= 0.8 * f128;
+    if (use_256 && k64 && N % 256 == 0 && M >= 4096 && K >= use_256 && fills) launch_nt<256, 256, 64, 4, 2>(g, stream);
     else if (use_3wg && !n96 && K % 32 == 0 && K < k3_max) launch_nt<128, 128, 32, 2, 3>(g, stream);
     else if (use_big && k64 && !n96 && M >= 4096 && K >= kbig_min) launch_nt<256, 128, 64, 4, 3>(g, stream);
     else if (n96) { if (k64) launch_nt<128, 96, 64, 2, 2>(g, stream); else launch_nt<128, 96, 32, 2, 2>(g, stream); }
