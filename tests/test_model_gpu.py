@@ -181,3 +181,36 @@ def test_prompt_classifier_zero_shot_scores(dev, monkeypatch):
     # default construction on an offline box: hashed stand-in ids, same call path
     out2 = PromptClassifier(model)(feats[:1], classes[:2], visualize=False)
     assert out2["classes_similarities"].shape == (1, 2)
+
+
+@pytest.mark.parametrize("n,S", [(1, 77), (3, 256), (5, 40)])
+def test_ragged_and_degenerate_batches(dev, monkeypatch, n, S):
+    """Batch of one, odd batch sizes, the reference's default sequence length (256, configs/tokenizer/bert_clinical.yaml) and
+    prompts of length 2 ([CLS][SEP] only) next to full-length ones: pixel-mode step end to end vs the oracle."""
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    _small_bert(monkeypatch)
+    torch.manual_seed(0)
+    model = MMGCLIP(_cfg("networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical", f"tokenizer.config.sequence_length={S}",
+                         "networks/dropout=dropout0", "networks.image_encoder.micro_batch=2", "networks.image_encoder.image_size=64")).train()
+    batch = synthetic_batch(n, S=S, image_size=64, vocab_size=3000, seed=7)
+    tok = batch["text_tokens"]
+    tok["input_ids"][0, 1] = 102                 # first prompt: [CLS][SEP] only
+    tok["input_ids"][0, 2:] = 0
+    tok["attention_mask"][0, 2:] = 0
+    if n > 1:                                    # last prompt: every position used
+        tok["attention_mask"][n - 1, :] = 1
+        tok["input_ids"][n - 1, 1:S - 1] = 1234
+        tok["input_ids"][n - 1, S - 1] = 102
+    ref = _oracle_outputs(model, {"image": batch["image"], "text_tokens": tok}, pixels=True)
+    out = model(batch)
+    assert out["logits_per_image"].shape == (n, n)
+    np.testing.assert_allclose(out["logits_per_image"].detach().cpu().numpy(), ref["logits_per_image"].numpy(), atol=0.25)
+    loss, labels = create_loss("CLIPLoss")()(**out)
+    ref_loss, _ = O.clip_loss(ref["logits_per_image"], ref["logits_per_text"])
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * max(abs(ref_loss.item()), 0.1)
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    fused, _ = create_loss("CLIPLoss")()(**model(batch, materialize_logits=False))
+    assert abs(fused.item() - loss.item()) < 1e-4 * max(abs(loss.item()), 0.1)
