@@ -24,6 +24,7 @@
 // stage the halo tile of image n (tile origin h0,w0; channel slab c0) into LDS, zero outside the image.
 // All of a lane's 16-byte loads are issued before the first LDS store: one memory latency per tile instead of one per
 // chunk (the chunk-by-chunk loop made staging 3x longer than the 49-tap arithmetic).
+template <int ROWD = DW_ROWD>
 __device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ x, unsigned* tile, int n, int H, int W, int C, int h0,
                                          int w0, int c0) {
     constexpr int CHUNKS = DW_ROWS * DW_COLS * (DW_CB / 8);
@@ -37,7 +38,7 @@ __device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ x, unsigned*
         const int col = pix % DW_COLS, row = pix / DW_COLS;
         const int gh = h0 - 3 + row, gw = w0 - 3 + col;
         v[it] = make_uint4(0, 0, 0, 0);
-        dst[it] = idx < CHUNKS ? row * DW_ROWD + col * (DW_CB / 2) + ch * 4 : -1;
+        dst[it] = idx < CHUNKS ? row * ROWD + col * (DW_CB / 2) + ch * 4 : -1;
         if (idx < CHUNKS && gh >= 0 && gh < H && gw >= 0 && gw < W)
             v[it] = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + gh) * W + gw) * C + c0 + ch * 8);
     }
@@ -117,6 +118,99 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restric
                 if (gw < W) {
                     const size_t off = (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp;
                     const unsigned o = pack2bf(a0[p] + bf2f_lo(addv[p]), a1[p] + bf2f_hi(addv[p]));
+                    if (nt) __builtin_nontemporal_store(o, reinterpret_cast<unsigned*>(y + off));
+                    else *reinterpret_cast<unsigned*>(y + off) = o;
+                }
+            }
+        }
+    }
+}
+
+// Two output rows per lane.  A lane of the kernel above unpacks every input row it reads (a shift or a mask per bf16: 196 of
+// its 980 VALU operations per pass) for ONE output row; here rows 2*r4 and 2*r4+1 share their 8 input rows, so a tile costs
+// 224 unpacks + 1568 FMAs per lane instead of 392 + 1568, in one pass.  Every output accumulates its 49 taps in the same
+// (kh, kw) order as above: bit-identical results.  The row pitch is 616 dwords so that the four row groups of a wave, now
+// two rows apart, still start 16 banks apart.
+#define DW_ROWD2 (DW_COLS * (DW_CB / 2) + 8)
+template <bool FLIP>
+__global__ __launch_bounds__(256, 2) void dwconv7_rows2_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const bf16_t* __restrict__ add,
+                                                               bf16_t* __restrict__ y, int H, int W, int C, int tiles_w, int nt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+    unsigned* tile = smem_u;                                              // [DW_ROWS][DW_ROWD2] dwords (bf16 pairs)
+    float* ws = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD2);    // [49][32]
+    const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+    const int c0 = blockIdx.y * DW_CB, n = blockIdx.z;
+    const int h0 = th * DW_TH, w0 = tw * DW_TW;
+    const int cp = threadIdx.x & 15, r4 = (threadIdx.x >> 4) & 3, strip = threadIdx.x >> 6;
+
+    for (int i = threadIdx.x; i < 49 * DW_CB; i += 256) {
+        const int k = i / DW_CB, c = i % DW_CB;
+        ws[i] = w[(size_t)(FLIP ? 48 - k : k) * C + c0 + c];
+    }
+    dw_stage<DW_ROWD2>(x, tile, n, H, W, C, h0, w0, c0);
+    __syncthreads();
+
+    const float b0 = bias ? bias[c0 + 2 * cp] : 0.f, b1 = bias ? bias[c0 + 2 * cp + 1] : 0.f;
+    const int oh = 2 * r4;
+    unsigned addv[2][8];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int gh = h0 + oh + rr, gw = w0 + strip * 8 + p;
+            addv[rr][p] = (add && gh < H && gw < W) ? *reinterpret_cast<const unsigned*>(add + (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp) : 0u;
+        }
+    float a0[2][8], a1[2][8];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { a0[rr][p] = b0; a1[rr][p] = b1; }
+    const unsigned* base = tile + oh * DW_ROWD2 + (strip * 8) * (DW_CB / 2) + cp;
+    const float* wbase = ws + 2 * cp;
+    // input row r (0..7 below the pair's first output row) feeds output row 0 with kernel row r and output row 1 with kernel
+    // row r-1.  Rolled loop (hipcc hoists every row's LDS reads to the top and spills when it is fully unrolled).
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+        unsigned in[14];
+        float f0[14], f1[14];
+#pragma unroll
+        for (int q = 0; q < 14; ++q) in[q] = base[r * DW_ROWD2 + q * (DW_CB / 2)];
+#pragma unroll
+        for (int q = 0; q < 14; ++q) { f0[q] = bf2f_lo(in[q]); f1[q] = bf2f_hi(in[q]); }
+        if (r < 7) {
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float2 wt = *reinterpret_cast<const float2*>(wbase + (r * 7 + kw) * DW_CB);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    a0[0][p] = fmaf(wt.x, f0[p + kw], a0[0][p]);
+                    a1[0][p] = fmaf(wt.y, f1[p + kw], a1[0][p]);
+                }
+            }
+        }
+        if (r > 0) {
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const float2 wt = *reinterpret_cast<const float2*>(wbase + ((r - 1) * 7 + kw) * DW_CB);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    a0[1][p] = fmaf(wt.x, f0[p + kw], a0[1][p]);
+                    a1[1][p] = fmaf(wt.y, f1[p + kw], a1[1][p]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int gh = h0 + oh + rr;
+        if (gh < H) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int gw = w0 + strip * 8 + p;
+                if (gw < W) {
+                    const size_t off = (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp;
+                    const unsigned o = pack2bf(a0[rr][p] + bf2f_lo(addv[rr][p]), a1[rr][p] + bf2f_hi(addv[rr][p]));
                     if (nt) __builtin_nontemporal_store(o, reinterpret_cast<unsigned*>(y + off));
                     else *reinterpret_cast<unsigned*>(y + off) = o;
                 }
@@ -210,6 +304,95 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_kernel(const bf16_t* __r
     }
 }
 
+// Weight gradient with two dy rows per lane (same idea as dwconv7_rows2_kernel: the 8 input rows under a row pair are read
+// and unpacked once for both).  Input row r meets dy row 0 at kernel row r and dy row 1 at kernel row r-1.
+__global__ __launch_bounds__(256, 1) void dwconv7_wgrad_rows2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                     float* __restrict__ dw, float* __restrict__ dbias, int N,
+                                                                     int H, int W, int C, int tiles_w, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+    unsigned* tile = smem_u;
+    float* red = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD2);    // [4 waves][50][32]
+    const int c0 = blockIdx.y * DW_CB;
+    const int cp = threadIdx.x & 15, r4 = (threadIdx.x >> 4) & 3, strip = threadIdx.x >> 6;
+    const int oh = 2 * r4;
+
+    float d0[49], d1[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) { d0[k] = 0.f; d1[k] = 0.f; }
+    float sb0 = 0.f, sb1 = 0.f;
+
+    for (int item = blockIdx.x; item < N * tiles; item += gridDim.x) {
+        const int n = item / tiles, tl = item - n * tiles;
+        const int tw = tl % tiles_w, th = tl / tiles_w;
+        const int h0 = th * DW_TH, w0 = tw * DW_TW;
+        __syncthreads();
+        dw_stage<DW_ROWD2>(x, tile, n, H, W, C, h0, w0, c0);
+        float g0[2][8], g1[2][8];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int gh = h0 + oh + rr, gw = w0 + strip * 8 + p;
+                unsigned v = 0;
+                if (gh < H && gw < W) v = *reinterpret_cast<const unsigned*>(dy + (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp);
+                g0[rr][p] = bf2f_lo(v);
+                g1[rr][p] = bf2f_hi(v);
+                sb0 += g0[rr][p];
+                sb1 += g1[rr][p];
+            }
+        __syncthreads();
+        const unsigned* base = tile + oh * DW_ROWD2 + (strip * 8) * (DW_CB / 2) + cp;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float i0[14], i1[14];
+#pragma unroll
+            for (int q = 0; q < 14; ++q) {
+                const unsigned v = base[r * DW_ROWD2 + q * (DW_CB / 2)];
+                i0[q] = bf2f_lo(v);
+                i1[q] = bf2f_hi(v);
+            }
+            if (r < 7) {
+#pragma unroll
+                for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        d0[r * 7 + kw] = fmaf(i0[p + kw], g0[0][p], d0[r * 7 + kw]);
+                        d1[r * 7 + kw] = fmaf(i1[p + kw], g1[0][p], d1[r * 7 + kw]);
+                    }
+            }
+            if (r > 0) {
+#pragma unroll
+                for (int kw = 0; kw < 7; ++kw)
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        d0[(r - 1) * 7 + kw] = fmaf(i0[p + kw], g0[1][p], d0[(r - 1) * 7 + kw]);
+                        d1[(r - 1) * 7 + kw] = fmaf(i1[p + kw], g1[1][p], d1[(r - 1) * 7 + kw]);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 49; ++k) {
+        d0[k] += __shfl_xor(d0[k], 16, 64); d0[k] += __shfl_xor(d0[k], 32, 64);
+        d1[k] += __shfl_xor(d1[k], 16, 64); d1[k] += __shfl_xor(d1[k], 32, 64);
+    }
+    sb0 += __shfl_xor(sb0, 16, 64); sb0 += __shfl_xor(sb0, 32, 64);
+    sb1 += __shfl_xor(sb1, 16, 64); sb1 += __shfl_xor(sb1, 32, 64);
+    if (r4 == 0) {
+        float* rw = red + strip * 50 * DW_CB;
+#pragma unroll
+        for (int k = 0; k < 49; ++k) *reinterpret_cast<float2*>(rw + k * DW_CB + 2 * cp) = make_float2(d0[k], d1[k]);
+        *reinterpret_cast<float2*>(rw + 49 * DW_CB + 2 * cp) = make_float2(sb0, sb1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 50 * DW_CB; i += 256) {
+        const float v = red[i] + red[50 * DW_CB + i] + red[2 * 50 * DW_CB + i] + red[3 * 50 * DW_CB + i];
+        if (i < 49 * DW_CB) atomicAdd(dw + (size_t)(i / DW_CB) * C + c0 + (i % DW_CB), v);
+        else if (dbias) atomicAdd(dbias + c0 + (i - 49 * DW_CB), v);
+    }
+}
+
 static int dw_check(const char* who, int n, int H, int W, int C) {
     MMG_CHECK_ARG(n > 0 && H > 0 && W > 0 && C > 0 && C % DW_CB == 0 && n <= 65535 && C / DW_CB <= 65535,
                   "%s: n=%d H=%d W=%d C=%d (C must be a multiple of 32)", who, n, H, W, C);
@@ -237,6 +420,21 @@ MMG_API int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, c
     const size_t shm = (size_t)DW_ROWS * DW_ROWD * 4 + 49 * DW_CB * 4;
     const dim3 grid(tiles_w * tiles_h, C / DW_CB, n);
     const int nt = (size_t)n * H * W * C * 2 >= ((size_t)256 << 20);
+    const int rows2 = getenv("MMG_DWCONV_ROWS2") ? atoi(getenv("MMG_DWCONV_ROWS2")) : 1;      // read per call (tests / A-B runs)
+    if (rows2) {
+        const size_t shm2 = (size_t)DW_ROWS * DW_ROWD2 * 4 + 49 * DW_CB * 4;
+        if (flip) {
+            mmg_allow_lds(dwconv7_rows2_kernel<true>, shm2);
+            hipLaunchKernelGGL(dwconv7_rows2_kernel<true>, grid, dim3(256), shm2, stream, (const bf16_t*)x, w, bias,
+                               (const bf16_t*)add, (bf16_t*)y, H, W, C, tiles_w, nt);
+        } else {
+            mmg_allow_lds(dwconv7_rows2_kernel<false>, shm2);
+            hipLaunchKernelGGL(dwconv7_rows2_kernel<false>, grid, dim3(256), shm2, stream, (const bf16_t*)x, w, bias,
+                               (const bf16_t*)add, (bf16_t*)y, H, W, C, tiles_w, nt);
+        }
+        MMG_LAUNCH_CHECK("mmg_dwconv7_nhwc");
+        return 0;
+    }
     if (flip) {
         mmg_allow_lds(dwconv7_kernel<true>, shm);
         hipLaunchKernelGGL(dwconv7_kernel<true>, grid, dim3(256), shm, stream, (const bf16_t*)x, w, bias, (const bf16_t*)add,
@@ -267,6 +465,15 @@ MMG_API int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* d
     if (align8 && per_slab >= 8) per_slab &= ~7;
     if (per_slab < 1) per_slab = 1;
     if (per_slab > n * tiles) per_slab = n * tiles;
+    const int rows2 = getenv("MMG_DWCONV_ROWS2") ? atoi(getenv("MMG_DWCONV_ROWS2")) : 1;
+    if (rows2) {
+        const size_t shm2 = (size_t)DW_ROWS * DW_ROWD2 * 4 + 4 * 50 * DW_CB * 4;
+        mmg_allow_lds(dwconv7_wgrad_rows2_kernel, shm2);
+        hipLaunchKernelGGL(dwconv7_wgrad_rows2_kernel, dim3(per_slab, slabs), dim3(256), shm2, stream, (const bf16_t*)x,
+                           (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w, tiles);
+        MMG_LAUNCH_CHECK("mmg_dwconv7_wgrad");
+        return 0;
+    }
     mmg_allow_lds(dwconv7_wgrad_kernel, shm);
     hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3(per_slab, slabs), dim3(256), shm, stream, (const bf16_t*)x,
                        (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w, tiles);

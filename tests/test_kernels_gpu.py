@@ -1,5 +1,6 @@
 """HBM-bound / conv / attention kernels vs plain PyTorch fp32 references of the same ops (bf16-rounded inputs)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -109,7 +110,7 @@ def test_adamw_matches_torch(dev):
 
 
 @pytest.mark.parametrize("n,H,W,C", [(2, 32, 32, 96), (1, 56, 56, 96), (2, 14, 14, 384), (3, 7, 7, 768), (1, 64, 40, 192), (2, 37, 50, 64)])
-def test_dwconv7(dev, n, H, W, C):
+def test_dwconv7(dev, n, H, W, C, monkeypatch):
     from mmgclip import kernels as K
     x = _r((n, H, W, C), dev, 16).to(BF)
     w = _r((C, 1, 7, 7), dev, 17, 0.1)
@@ -126,15 +127,22 @@ def test_dwconv7(dev, n, H, W, C):
     res = _r((n * H * W, C), dev, 20).to(BF)
     dx = K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True)
     _close(dx.reshape(n, H, W, C), xr.grad.permute(0, 2, 3, 1) + res.float().reshape(n, H, W, C), 1e-2, 3e-2)
+    # the other row blocking (one / two output rows per lane) accumulates every output in the same order: bit-identical
+    monkeypatch.setenv("MMG_DWCONV_ROWS2", "0" if os.environ.get("MMG_DWCONV_ROWS2", "1") != "0" else "1")
+    assert torch.equal(K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C), y)
+    assert torch.equal(K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True), dx)
+    monkeypatch.undo()
     # the matrix-core formulation of the same two launches (Toeplitz-operand MFMAs, taps in bf16)
     y2 = K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C, mfma=True)
     _close(y2.reshape(n, H, W, C), ref.permute(0, 2, 3, 1), 1e-2, 3e-2)
     dx2 = K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True, mfma=True)
     _close(dx2.reshape(n, H, W, C), xr.grad.permute(0, 2, 3, 1) + res.float().reshape(n, H, W, C), 1e-2, 4e-2)
-    dw, db = torch.zeros(49, C, device=dev), torch.zeros(C, device=dev)
-    K.dwconv7_wgrad(x.reshape(-1, C), dy.reshape(-1, C), dw, db, n, H, W, C)
-    _close(dw, wr.grad.reshape(C, 49).t(), 2e-3, 2e-3 * (n * H * W) ** 0.5)
-    _close(db, br.grad, 2e-3, 2e-3 * (n * H * W) ** 0.5)
+    for rows2 in ("1", "0"):                      # two dy rows per lane (default) / one
+        monkeypatch.setenv("MMG_DWCONV_ROWS2", rows2)
+        dw, db = torch.zeros(49, C, device=dev), torch.zeros(C, device=dev)
+        K.dwconv7_wgrad(x.reshape(-1, C), dy.reshape(-1, C), dw, db, n, H, W, C)
+        _close(dw, wr.grad.reshape(C, 49).t(), 2e-3, 2e-3 * (n * H * W) ** 0.5)
+        _close(db, br.grad, 2e-3, 2e-3 * (n * H * W) ** 0.5)
 
 
 def _attn_ref(qkv, mask, B, S, heads):
