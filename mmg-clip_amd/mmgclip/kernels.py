@@ -2,6 +2,8 @@
 
 Shapes follow the device layout: activations are bf16 row-major [rows, channels] (NHWC flattened for images).
 """
+import os
+
 import torch
 
 from . import _hip
@@ -114,14 +116,16 @@ def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0)
 def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None, mfma=False):
     y = out if out is not None else torch.empty(n * H * W, C, device=x.device, dtype=BF16)
     px = n * H * W * C
-    PROFILE.timed("dwconv7_kernel", 98.0 * px, (6 if add is not None else 4) * px,
+    fam = "dwconv7_mfma_kernel" if mfma else ("dwconv7_rows2_kernel" if os.environ.get("MMG_DWCONV_ROWS2", "1") != "0" else "dwconv7_kernel")
+    PROFILE.timed(fam, 98.0 * px, (6 if add is not None else 4) * px,
                   lambda: call("mmg_dwconv7_nhwc_mfma" if mfma else "mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()))
     return y
 
 
 def dwconv7_wgrad(x, dy, dw49, dbias, n, H, W, C):
     px = n * H * W * C
-    PROFILE.timed("dwconv7_wgrad_kernel", 98.0 * px, 4 * px,
+    fam = "dwconv7_wgrad_rows2_kernel" if os.environ.get("MMG_DWCONV_ROWS2", "1") != "0" else "dwconv7_wgrad_kernel"
+    PROFILE.timed(fam, 98.0 * px, 4 * px,
                   lambda: call("mmg_dwconv7_wgrad", ptr(x), ptr(dy), ptr(dw49), ptr(dbias), n, H, W, C, stream()))
 
 
