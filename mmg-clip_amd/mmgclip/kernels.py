@@ -190,8 +190,10 @@ def attention_fwd(qkv, mask, B, S, heads, want_lse=True, force_long=False, cu=No
     if cu is not None:
         call("mmg_attention_varlen_fwd", ptr(qkv), qkv.stride(0), ptr(cu), ptr(ctx), Hd, ptr(lse), B, S, heads, Hd, 0.125, stream())
         return ctx, lse
-    name = "mmg_attention_long_fwd" if (force_long or S > 512) else "mmg_attention_fwd"
-    call(name, ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), Hd, ptr(lse), B, S, heads, Hd, 0.125, stream())
+    long_path = force_long or S > 512
+    name = "mmg_attention_long_fwd" if long_path else "mmg_attention_fwd"
+    PROFILE.timed("attn_flash_fwd_kernel" if long_path else "attn_fwd_kernel", 4.0 * B * heads * S * S * 64, 8 * B * S * Hd,
+                  lambda: call(name, ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), Hd, ptr(lse), B, S, heads, Hd, 0.125, stream()))
     return ctx, lse
 
 
@@ -204,8 +206,10 @@ def attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, out=None, force_long=F
         return dqkv
     if force_long or S > 256:
         delta = torch.empty(B * heads * S, device=qkv.device, dtype=torch.float32)
-        call("mmg_attention_long_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),
-             dctx.stride(0), ptr(dqkv), dqkv.stride(0), ptr(delta), B, S, heads, Hd, 0.125, stream())
+        # (one family for the three launches of the tiled backward: delta, dQ, dK/dV)
+        PROFILE.timed("attn_flash_bwd_kernels", 10.0 * B * heads * S * S * 64, 22 * B * S * Hd,
+                      lambda: call("mmg_attention_long_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse),
+                                   ptr(dctx), dctx.stride(0), ptr(dqkv), dqkv.stride(0), ptr(delta), B, S, heads, Hd, 0.125, stream()))
     else:
         call("mmg_attention_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),
              dctx.stride(0), ptr(dqkv), dqkv.stride(0), B, S, heads, Hd, 0.125, stream())
