@@ -853,7 +853,8 @@ MMG_API int mmg_attention_long_bwd(const void* qkv, int ld, const long long* mas
     const int rbk_env = getenv("MMG_ATT_RB_DKV") ? atoi(getenv("MMG_ATT_RB_DKV")) : (rbq_env > 2 ? 2 : rbq_env);
     const long bhn = (long)B * heads;
     const int rbq = rbq_env ? rbq_env : (bhn * cdiv(S, 256) >= 1024 ? 4 : bhn * cdiv(S, 128) >= 1024 ? 2 : 1);
-    const int rbk = rbk_env ? rbk_env : (bhn * cdiv(S, 128) >= 1024 ? 2 : 1);
+    // dK/dV holds two accumulator sets per row block: 3 blocks per wave is what fits 256 registers (measured -4 % vs 2)
+    const int rbk = rbk_env ? rbk_env : (bhn * cdiv(S, 192) >= 1024 ? 3 : bhn * cdiv(S, 128) >= 1024 ? 2 : 1);
     const float* dws = (const float*)delta_ws;
     a.nbh = (int)bhn;
 #define ATT_BWD(KERNEL, RBV)                                                                                   \
@@ -864,7 +865,7 @@ MMG_API int mmg_attention_long_bwd(const void* qkv, int ld, const long long* mas
         else hipLaunchKernelGGL((KERNEL<RBV, false>), grid, dim3(256), 0, stream, a, dws);                     \
     } while (0)
     if (rbq == 4) ATT_BWD(attn_flash_dq_kernel, 4); else if (rbq == 2) ATT_BWD(attn_flash_dq_kernel, 2); else ATT_BWD(attn_flash_dq_kernel, 1);
-    if (rbk == 2) ATT_BWD(attn_flash_dkv_kernel, 2); else ATT_BWD(attn_flash_dkv_kernel, 1);
+    if (rbk == 3) ATT_BWD(attn_flash_dkv_kernel, 3); else if (rbk == 2) ATT_BWD(attn_flash_dkv_kernel, 2); else ATT_BWD(attn_flash_dkv_kernel, 1);
 #undef ATT_BWD
     MMG_LAUNCH_CHECK("mmg_attention_long_bwd");
     return 0;

@@ -216,14 +216,16 @@ def test_bert_embeddings_and_eos_pool(dev):
     assert torch.equal(dh, ref)
 
 
-@pytest.mark.parametrize("rb", [1, 2, 4])
+@pytest.mark.parametrize("rb", [1, 2, 4, 43])        # 43: 4 row blocks per wave in forward / dQ, 3 in dK/dV
 @pytest.mark.parametrize("B,S,heads,masked", [(2, 77, 3, True), (1, 300, 2, True), (1, 1025, 2, False), (2, 130, 1, False),
                                               (4, 700, 2, False), (2, 520, 4, True)])
 def test_attention_long_fwd_bwd(dev, B, S, heads, masked, rb, monkeypatch):
     """Flash-style tiled kernels (any S) vs the fp32 reference, incl. a ragged last tile, a key-padding mask, every rows-per-wave
     variant (16 * rb query rows / keys per wave) and both workgroup orders (B * heads a multiple of 8: XCD-grouped)."""
     from mmgclip import kernels as K
-    monkeypatch.setenv("MMG_ATT_RB", str(rb))
+    monkeypatch.setenv("MMG_ATT_RB", str(rb // 10 if rb > 9 else rb))
+    if rb > 9:
+        monkeypatch.setenv("MMG_ATT_RB_DKV", str(rb % 10))
     Hd = heads * 64
     qkv = _r((B * S, 3 * Hd), dev, 41).to(BF)
     mask = None

@@ -28,9 +28,13 @@ def timeit(fn, n=3):
     return s.elapsed_time(e) / n
 
 
-for rb in sys.argv[1:] or ["0"]:
+for spec in sys.argv[1:] or ["0"]:
+    rb, _, rbk = spec.partition(":")            # "4:3" = 4 row blocks per wave in fwd / dQ, 3 in dK/dV
     os.environ["MMG_ATT_RB"] = rb
+    os.environ.pop("MMG_ATT_RB_DKV", None)
+    if rbk:
+        os.environ["MMG_ATT_RB_DKV"] = rbk
     ctx, lse = K.attention_fwd(qkv, None, B, S, heads)
     tf = timeit(lambda: K.attention_fwd(qkv, None, B, S, heads))
     tb = timeit(lambda: K.attention_bwd(qkv, None, ctx, lse, dctx, B, S, heads))
-    print(f"RB={rb}: fwd {tf:7.2f} ms {flop_f / tf / 1e9:7.1f} TFLOP/s   bwd {tb:7.2f} ms {2.5 * flop_f / tb / 1e9:7.1f} TFLOP/s", flush=True)
+    print(f"RB={spec}: fwd {tf:7.2f} ms {flop_f / tf / 1e9:7.1f} TFLOP/s   bwd {tb:7.2f} ms {2.5 * flop_f / tb / 1e9:7.1f} TFLOP/s", flush=True)
