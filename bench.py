@@ -144,7 +144,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="image-text pairs per GPU")
     ap.add_argument("--image-size", type=int, default=1024)
     ap.add_argument("--seq-len", type=int, default=77)
-    ap.add_argument("--micro-batch", type=int, default=64)
+    ap.add_argument("--micro-batch", type=int, default=None,
+                    help="images per pass through the image tower; default 256 (= one pass) for ConvNeXt-T, 64 for the larger towers")
     ap.add_argument("--variant", default="tiny", choices=["tiny", "base", "vit_b16"],
                     help="image tower: ConvNeXt-T (headline C2), ConvNeXt-B (C5 shape, bf16), ViT-B/16 (C4 shape)")
     ap.add_argument("--checkpoint", action="store_true", help="gradient checkpointing of the image tower (micro-batch granularity)")
@@ -157,6 +158,11 @@ def main():
     if args.cpu_baseline_worker is not None:
         cpu_baseline_worker(args.cpu_baseline_worker)
         return
+    if args.micro_batch is None:
+        # measured at C2 (same box): 64 -> 669, 128 -> 685, 256 -> 690 pairs/s (101 / 109 / 126 GiB); ConvNeXt-B at 64 already
+        # peaks at 267 GiB
+        # (checkpointing frees memory per micro-batch, so it keeps several of them)
+        args.micro_batch = 256 if (args.variant == "tiny" and not args.checkpoint) else 64
 
     from mmgclip import distributed, linalg
     from mmgclip.dataset.synthetic import synthetic_batch
@@ -256,7 +262,8 @@ def main():
             # counters cannot be read from inside the process), corrected as MI355X_MICROARCH.md prescribes
             tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) \
                 if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-            default_cmd = (args.batch, args.image_size, args.seq_len, args.micro_batch, args.variant, world) == (256, 1024, 77, 64, "tiny", 1)
+            default_cmd = (args.batch, args.image_size, args.seq_len, args.micro_batch, args.variant, world, args.checkpoint, args.fp8) == \
+                (256, 1024, 77, 256, "tiny", 1, False, False)
             traffic = json.load(open(os.path.join(ROOT, "profiles", tfile[-1]))).get("families", {}) if (tfile and default_cmd) else {}
             lines = []
             for fam, st in fams.items():

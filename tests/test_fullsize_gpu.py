@@ -44,6 +44,33 @@ def test_convnext_1024_micro_batch_independence_and_fused_vs_gemm_pair(dev, monk
     assert worst[0] < 6e-2, worst
 
 
+def test_convnext_256_images_in_one_micro_batch_equals_four_of_64(dev):
+    """The benchmarked configuration: 256 images of 1024^2 as ONE micro-batch.  Its stage-1 hidden tensors hold
+    256 * 65536 * 384 = 6.4e9 elements (> 2^32), so this is also the addressing test of every kernel on the path: features
+    and parameter gradients must equal those of four 64-image micro-batches."""
+    from mmgclip.networks.encoder import ConvNextTinyEncoder
+    torch.manual_seed(0)
+    img = torch.rand(256, 1, 1024, 1024, generator=torch.Generator().manual_seed(1)).to(dev)
+    wgt = torch.randn(256, 768, generator=torch.Generator().manual_seed(2)).to(dev)
+    state = None
+    results = {}
+    for mb in (256, 64):
+        tower = ConvNextTinyEncoder(micro_batch=mb)
+        if state is None:
+            state = {k: v.clone() for k, v in tower.state_dict().items()}
+        tower.load_state_dict(state)
+        tower = tower.to(dev)
+        feat = tower(img)
+        (feat * wgt).sum().backward()
+        results[mb] = (feat.detach().clone(), {n: p.grad.detach().clone() for n, p in tower.model.named_parameters()})
+        del tower, feat
+        torch.cuda.empty_cache()
+    assert torch.isfinite(results[256][0]).all()
+    assert _rel(results[256][0], results[64][0]) < 1e-5
+    for n, g in results[256][1].items():
+        assert _rel(g, results[64][1][n]) < 2e-3, n
+
+
 def test_dwconv_and_gemm_linearity_on_stage1_geometry(dev):
     """conv(a x1 + x2) = a conv(x1) + conv(x2) (no bias) and the same for the NT GEMM, on one image of the 256 x 256 x 96 map."""
     from mmgclip import kernels as K, linalg as L
