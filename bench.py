@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=1024)
     ap.add_argument("--seq-len", type=int, default=77)
     ap.add_argument("--micro-batch", type=int, default=None,
-                    help="images per pass through the image tower; default 256 (= one pass) for ConvNeXt-T, 64 for the larger towers")
+                    help="images per pass through the image tower; default 256 (= one pass) for ConvNeXt-T and ViT-B/16, 64 for ConvNeXt-B and with --checkpoint")
     ap.add_argument("--variant", default="tiny", choices=["tiny", "base", "vit_b16"],
                     help="image tower: ConvNeXt-T (headline C2), ConvNeXt-B (C5 shape, bf16), ViT-B/16 (C4 shape)")
     ap.add_argument("--checkpoint", action="store_true", help="gradient checkpointing of the image tower (micro-batch granularity)")
@@ -162,7 +162,8 @@ def main():
         # measured at C2 (same box): 64 -> 669, 128 -> 685, 256 -> 690 pairs/s (101 / 109 / 126 GiB); ConvNeXt-B at 64 already
         # peaks at 267 GiB
         # (checkpointing frees memory per micro-batch, so it keeps several of them)
-        args.micro_batch = 256 if (args.variant == "tiny" and not args.checkpoint) else 64
+        # ViT-B/16: 161.6 / 163.4 / 163.7 pairs/s at 64 / 128 / 256 (191 / 194 / 201 GiB)
+        args.micro_batch = 256 if (args.variant in ("tiny", "vit_b16") and not args.checkpoint) else 64
 
     from mmgclip import distributed, linalg
     from mmgclip.dataset.synthetic import synthetic_batch
