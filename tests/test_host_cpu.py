@@ -78,3 +78,29 @@ def test_product_path_fails_loudly_without_gpu():
     from mmgclip import head
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         head.L2Normalize.apply(torch.randn(4, 64))
+
+
+def test_committed_bench_line_follows_the_driver_contract():
+    """profiles/r01_bench_default.json is a line `bench.py` printed on an MI355X: every key of the bench contract is present,
+    the roofline object is self-consistent and names a kernel of the committed rocprof summary."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = json.load(open(os.path.join(root, "profiles", "r01_bench_default.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["higher_is_better"] is True and b["scaling"] == "weak" and b["vs_baseline"] is None
+    assert b["data"] == "synthetic" and b["dtype"] == "bf16" and "workload" in b["config"] and "model" not in b["config"]
+    assert abs(b["value"] - b["config"]["global_batch"] / (b["ms_per_step"] / 1e3)) < 0.01 * b["value"]
+    r = b["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    stats = open(os.path.join(root, "profiles", "r01_bench_default_kernel_stats.csv")).read()
+    assert r["kernel"] in stats
+    c = b["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == b["unit"]
