@@ -1,16 +1,22 @@
-"""CPU oracle for the two encoder towers — TEST INFRASTRUCTURE ONLY (see oracle/clip_oracle.py header).
+"""CPU oracle for the encoder towers — TEST INFRASTRUCTURE ONLY (see oracle/clip_oracle.py header).
 
-PARITY UNPINNED for this file: the arithmetic of both towers lives in third-party packages that are not in the
-reference tree — torchvision 0.14.1 `ConvNeXt` (inside a TorchScript archive the repo does not ship; torchvision is
-not installed here) and transformers 4.41.0 `BertModel` (5.15 installed) — and the reference holds no golden output
-for either.  The restatements below follow the published module definitions and the call order at
-the reference's call sites:
+Pinning.  The arithmetic of the towers lives in third-party packages that are not in the reference tree — torchvision
+0.14.1 `ConvNeXt` (inside a TorchScript archive the repo does not ship; torchvision is not installed here) and `resnet50`,
+transformers 4.41.0 `BertModel` (5.15 installed) — and the reference holds no golden output for any of them,
+so the reference ITSELF cannot pin this file.  It is pinned against independent third-party implementations instead:
+tests/golden/make_golden_encoders.py runs transformers' `ConvNextModel`, `ViTModel`, `ResNetModel` and `BertModel` on seeded
+weights (tests/golden/recipes.py) at the full architectures (ConvNeXt-T 3/3/9/3, ViT-B/16, ResNet-50, BERT-base 12 layers) and
+stores their outputs and autograd gradients (tests/golden/g5_*.npz); g9_c1_step_s{77,256}.npz is BASELINE config C1 end to end
+(those towers -> the reference's own LinearProjectionLayer and CLIPLoss).  tests/test_oracle_encoders.py checks every function
+below against them (forward 2e-5, gradients 2e-4...5e-4 of the largest magnitude).  What stays unpinned: torchvision's own
+rounding order (same formulas, different kernels) and the private pretrained weights.
+
+The restatements follow the published module definitions and the call order at the reference's call sites:
     mmgclip/networks/encoder.py:40-55      ConvNextTiny.forward = model.features(x) -> model.avgpool(x)
     mmgclip/networks/image_features.py:95-99   x*65535 ; (x - 32767.5)/32767.5
+    mmgclip/networks/encoder.py:101-117    ResNet50Encoder.forward
     mmgclip/networks/encoder.py:146-156    BertEncoder.forward = model(**x)['last_hidden_state']
     notebooks/clf_convnext_tiny_experimental.ipynb cell 3   (module tree)   notebooks/bert_experimental.ipynb:609-624 (config)
-tests/test_oracle_encoders.py cross-checks the BERT restatement against the installed transformers BertModel (eager
-attention, dropout 0) and the ConvNeXt geometry against the notebook's printed shapes ([1,1,1906,818] -> [1,768,59,25]).
 """
 import math
 

@@ -26,6 +26,8 @@ import torch
 
 REF = os.environ.get("MMGCLIP_REFERENCE", "/root/reference")
 OUT = os.path.dirname(os.path.abspath(__file__))
+if OUT not in sys.path:
+    sys.path.insert(0, OUT)
 
 
 def load_by_path(name, rel):
@@ -264,6 +266,10 @@ def main():
     golden_schedule(sched)
     golden_early_stopper(es_mod)
     print("golden vectors written to", OUT)
+    # G5 / G9: encoder towers pinned by transformers' independent implementations (+ the reference's projection / loss for C1)
+    import make_golden_encoders
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    make_golden_encoders.main(proj, losses)
 
 
 if __name__ == "__main__":

@@ -76,3 +76,141 @@ def test_resnet50_oracle_equals_the_torch_modules_of_the_same_tree():
             assert torch.allclose(E.resnet50_forward(sd, x, train_bn=False), run(x), rtol=1e-4, atol=1e-5)
             m.train()
             assert torch.allclose(E.resnet50_forward(sd, x, train_bn=True), run(x), rtol=1e-3, atol=1e-4)
+
+
+# ---- pins: oracle vs outputs of transformers' ConvNextModel / ViTModel / ResNetModel / BertModel (tests/golden/g5_*, g9_*) ----
+import os                                                            # noqa: E402
+import sys                                                           # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import recipes as R                                                  # noqa: E402
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _close(got, want, rtol, what=""):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+    assert err <= rtol, f"{what}: max error {err:.3e} of the largest magnitude (allowed {rtol:.1e})"
+
+
+@pytest.mark.parametrize("name", ["g5_convnext_tiny.npz", "g5_convnext_small.npz"])
+def test_convnext_oracle_matches_third_party_golden(golden_dir, name):
+    """forward (`features`, `avgpool`) and parameter gradients of oracle.convnext_forward == transformers ConvNextModel on the
+    recipe weights, incl. the 3-channel odd-size net (77x50 -> stem floor(./4) -> ... the torch floor rule everywhere)."""
+    from mmgclip.networks import convnext as CN
+    g = _g(golden_dir, name)
+    seed, depths, dims = int(g["seed"]), tuple(int(v) for v in g["depths"]), tuple(int(v) for v in g["dims"])
+    n, cin, H, W = (int(v) for v in g["shape"])
+    CN.CONFIGS["_golden"] = dict(depths=depths, dims=dims)
+    feats = R.fill_(CN.build_features("_golden", cin), seed, "features.")
+    sd = {"features." + k: v for k, v in feats.named_parameters()}
+    img = R.structured_images(n, max(H, W), seed, cin)[:, :, :H, :W].contiguous()
+    assert abs(float(img.double().sum()) - float(g["image_sum"])) < 1e-6 * float(g["image_sum"])      # the recipe reproduced
+    pooled, fmap = E.convnext_forward(sd, img, depths=depths)
+    assert tuple(fmap.shape) == tuple(g["fmap_shape"])
+    _close(pooled.flatten(1).detach(), g["pooled"], 2e-5, "pooled")
+    _close(fmap[:, :, 0, 0].detach(), g["fmap_first"], 2e-5, "fmap[0,0]")
+    _close(fmap[:, :, -1, -1].detach(), g["fmap_last"], 2e-5, "fmap[-1,-1]")
+    (pooled.flatten(1) * torch.from_numpy(g["gy"])).sum().backward()
+    keys = [k[5:] for k in g.files if k.startswith("grad.")]
+    assert len(keys) > 20
+    for k in keys:
+        _close(sd[k].grad, g["grad." + k], 2e-4, k)
+
+
+def test_vit_oracle_matches_third_party_golden(golden_dir):
+    from mmgclip.networks.vit import _tv_layout
+    g = _g(golden_dir, "g5_vit_b16.npz")
+    seed, size = int(g["seed"]), int(g["image_size"])
+    tv = R.fill_(_tv_layout(size, 1, 768, 12, 3072, 16), seed)
+    sd = dict(tv.named_parameters())
+    img = R.structured_images(3, size, seed)
+    cls = E.vit_forward(sd, img)
+    _close(cls.detach(), g["cls"], 2e-5, "class token")
+    (cls * torch.from_numpy(g["gy"])).sum().backward()
+    for k in [k[5:] for k in g.files if k.startswith("grad.")]:
+        _close(sd[k].grad.reshape(g["grad." + k].shape), g["grad." + k], 2e-4, k)
+
+
+def test_resnet_oracle_matches_third_party_golden(golden_dir):
+    from mmgclip.networks.resnet import _TorchvisionResNet
+    g = _g(golden_dir, "g5_resnet50.npz")
+    seed = int(g["seed"])
+    sd = R.fill_(_TorchvisionResNet(), seed).state_dict()
+    img = R.structured_images(4, 64, seed, in_chans=3) * 2.0 - 1.0
+    with torch.no_grad():
+        _close(E.resnet50_forward(sd, img, train_bn=False), g["pooled_eval"], 5e-5, "eval-mode batch norm")
+        _close(E.resnet50_forward(sd, img, train_bn=True), g["pooled_train"], 5e-4, "train-mode batch norm")
+
+
+def test_bert_oracle_matches_third_party_golden(golden_dir):
+    """BERT-base (12 layers, vocab 28996) on ragged [4,77] and [2,256] batches, hidden state at [SEP] and [CLS]."""
+    from mmgclip.networks.bert import BertConfigLite, _hf_layout
+    g = _g(golden_dir, "g5_bert_base.npz")
+    sd = R.fill_(_hf_layout(BertConfigLite()), int(g["seed"])).state_dict()
+    for n, S in ((4, 77), (2, 256)):
+        ids, mask, tt = R.ragged_tokens(n, S, int(g["seed"]))
+        assert (ids.numpy() == g[f"ids_{S}"]).all() and (mask.numpy() == g[f"mask_{S}"]).all()
+        with torch.no_grad():
+            h = E.bert_forward(sd, ids, mask, tt)
+        from oracle import clip_oracle as O
+        _close(O.eos_pool(h, mask), g[f"eos_hidden_{S}"], 5e-5, f"[SEP] rows S={S}")
+        _close(h[:, 0], g[f"cls_hidden_{S}"], 5e-5, f"[CLS] rows S={S}")
+
+
+def c1_oracle_step(g, dtype=torch.float32):
+    """BASELINE config C1 through the oracle, on the recipe weights / inputs of tests/golden/g9_c1_step_s*.npz.
+    Returns (dict of outputs, dict name -> parameter with .grad)."""
+    from mmgclip.networks import convnext as CN
+    from mmgclip.networks.bert import BertConfigLite, _hf_layout
+    from oracle import clip_oracle as O
+    seed, S = int(g["seed"]), int(g["S"])
+    csd = {"features." + k: v for k, v in R.fill_(CN.build_features("tiny", 1), seed, "features.").named_parameters()}
+    bsd = dict(R.fill_(_hf_layout(BertConfigLite()), seed + 1).named_parameters())
+    wi = R.seeded_tensor("image_projection_layer.layer.weight", (512, 768), seed + 2).requires_grad_(True)
+    wt = R.seeded_tensor("text_projection_layer.layer.weight", (512, 768), seed + 2).requires_grad_(True)
+    ls = torch.tensor(float(np.log(1 / 0.07)), requires_grad=True)
+    img = R.structured_images(8, 224, seed)
+    ids, mask, tt = R.ragged_tokens(8, S, seed)
+    assert (ids.numpy() == g["ids"]).all()
+    pooled, _ = E.convnext_forward(csd, img)
+    pooled = pooled.flatten(1)
+    pooled.retain_grad()
+    tf = O.eos_pool(E.bert_forward(bsd, ids, mask, tt), mask)
+    tf.retain_grad()
+    out = O.forward_tail(O.linear_projection(pooled, wi), O.linear_projection(tf, wt), ls)
+    loss, _ = O.clip_loss(out["logits_per_image"], out["logits_per_text"])
+    loss.backward()
+    out.update(loss=loss, pooled=pooled, text_features=tf)
+    params = {"image." + k: v for k, v in csd.items()}
+    params.update({"text." + k: v for k, v in bsd.items()})
+    params.update(wi=wi, wt=wt, ls=ls)
+    return out, params
+
+
+@pytest.mark.parametrize("S", [77, 256])
+def test_c1_step_oracle_matches_third_party_and_reference_golden(golden_dir, S):
+    """SURVEY §8c / BASELINE C1: n = 8, 224x224, ConvNeXt-T + BERT-base + LinearProjectionLayer + CLIPLoss, forward and backward.
+    Golden = transformers towers + the reference's own projection / loss classes (tests/golden/make_golden_encoders.py)."""
+    g = _g(golden_dir, f"g9_c1_step_s{S}.npz")
+    out, params = c1_oracle_step(g)
+    _close(out["pooled"].detach(), g["pooled"], 2e-5, "image features")
+    _close(out["text_features"].detach(), g["text_features"], 5e-5, "text features")
+    _close(out["logits_per_image"].detach(), g["logits_per_image"], 2e-5, "logits_per_image")
+    _close(out["logits_per_text"].detach(), g["logits_per_text"], 2e-5, "logits_per_text")
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert np.ptp(g["logits_per_image"]) > 1.0                       # the structured inputs give the logits real spread
+    _close(out["pooled"].grad, g["d_pooled"], 2e-4, "d image features")
+    _close(out["text_features"].grad, g["d_text_features"], 2e-4, "d text features")
+    _close(params["ls"].grad, g["d_logit_scale"], 2e-4, "d logit_scale")
+    _close(params["wi"].grad[:16], g["d_image_projection_rows"], 2e-4, "d image projection")
+    _close(params["wt"].grad[:16], g["d_text_projection_rows"], 2e-4, "d text projection")
+    keys = [k[5:] for k in g.files if k.startswith("grad.") and not k.endswith(".rows")]
+    assert len(keys) > 100
+    for k in keys:
+        _close(params[k].grad, g["grad." + k], 5e-4, k)
+    rows = torch.from_numpy(g["word_rows"])
+    _close(params["text.embeddings.word_embeddings.weight"].grad[rows], g["grad.text.embeddings.word_embeddings.weight.rows"], 5e-4, "word rows")
