@@ -820,6 +820,17 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkv_kernel(const AttArgs a,
     }
 }
 
+// Rows-per-wave override from the environment (a test / tuning knob), snapped to a value that has a kernel instantiation:
+// the launch grid is sized from this number, so it must be the template argument actually dispatched.  0 = no override.
+static int att_rb_env(const char* name, int max_rb) {
+    const char* e = getenv(name);
+    if (!e) return 0;
+    const int v = atoi(e);
+    if (v <= 0) return 0;                       // unparsable or non-positive: use the built-in choice
+    if (v >= max_rb) return max_rb;             // forward / dQ: 1, 2, 4; dK/dV: 1, 2, 3
+    return v == 3 ? 2 : v;                      // (3 only exists for dK/dV, where max_rb == 3 catches it above)
+}
+
 // Tiled (flash-style) attention for any S: same contract as mmg_attention_fwd.
 MMG_API int mmg_attention_long_fwd(const void* qkv, int ld, const long long* mask, void* ctx, int ldc, float* lse, int B, int S,
                                    int heads, int Hd, float scale, hipStream_t stream) {
@@ -829,7 +840,7 @@ MMG_API int mmg_attention_long_fwd(const void* qkv, int ld, const long long* mas
     a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = lse;
     a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
     // 64 rows per wave (4 row blocks) once there are enough query blocks to fill the GPU twice over, else 32 / 16
-    const int rb_env = getenv("MMG_ATT_RB") ? atoi(getenv("MMG_ATT_RB")) : 0;      // (read per call: the tests walk through 1 / 2 / 4)
+    const int rb_env = att_rb_env("MMG_ATT_RB", 4);      // (read per call: the tests walk through 1 / 2 / 4)
     const long bhn = (long)B * heads;
     const int rb = rb_env ? rb_env : (bhn * cdiv(S, 256) >= 1024 ? 4 : bhn * cdiv(S, 128) >= 1024 ? 2 : 1);
     a.nbh = (int)bhn; a.nblk = cdiv(S, 64 * rb);
@@ -860,8 +871,8 @@ MMG_API int mmg_attention_long_bwd(const void* qkv, int ld, const long long* mas
     int blocks = (int)((rows + 31) / 32 > 8192 ? 8192 : (rows + 31) / 32);          // 32 (row, head) pairs per workgroup
     hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)ctx, ldc, (const bf16_t*)dctx, lddc,
                        delta_ws, B, S, heads);
-    const int rbq_env = getenv("MMG_ATT_RB") ? atoi(getenv("MMG_ATT_RB")) : 0;
-    const int rbk_env = getenv("MMG_ATT_RB_DKV") ? atoi(getenv("MMG_ATT_RB_DKV")) : (rbq_env > 2 ? 2 : rbq_env);
+    const int rbq_env = att_rb_env("MMG_ATT_RB", 4);
+    const int rbk_env = getenv("MMG_ATT_RB_DKV") ? att_rb_env("MMG_ATT_RB_DKV", 3) : (rbq_env > 2 ? 2 : rbq_env);
     const long bhn = (long)B * heads;
     const int rbq = rbq_env ? rbq_env : (bhn * cdiv(S, 256) >= 1024 ? 4 : bhn * cdiv(S, 128) >= 1024 ? 2 : 1);
     // dK/dV holds two accumulator sets per row block: 3 blocks per wave is what fits 256 registers (measured -4 % vs 2)

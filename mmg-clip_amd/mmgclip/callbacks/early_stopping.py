@@ -6,8 +6,9 @@ class EarlyStopper:
     mmgclip/callbacks/early_stopping.py:5-66 ({'epoch','model_state_dict','optimizer_state_dict','val_loss',
     'best_score','counter'}, extra `<epoch>_model.pth` every 100 epochs)."""
 
-    def __init__(self, patience=5, verbose=False, delta=0, trace_func=print):
+    def __init__(self, patience=5, verbose=False, delta=0, trace_func=print, save=True):
         self.patience, self.verbose, self.delta, self.trace_func = patience, verbose, delta, trace_func
+        self.save = save          # additive: False on the non-zero ranks of a data-parallel run (one writer per file)
         self.counter = 0
         self.best_score = None
         self.early_stop = False
@@ -30,6 +31,9 @@ class EarlyStopper:
 
     def save_checkpoint(self, valid_loss, model, optimizer, epoch, path):
         self.trace_func(f"Valid loss improved from {self.val_loss_min:.6f} to {valid_loss:.6f}. Saving model ...")
+        if not self.save:
+            self.val_loss_min = valid_loss
+            return
         checkpoint = {'epoch': epoch, 'model_state_dict': model.state_dict(), 'optimizer_state_dict': optimizer.state_dict(),
                       'val_loss': valid_loss, 'best_score': self.best_score, 'counter': self.counter}
         torch.save(checkpoint, path)

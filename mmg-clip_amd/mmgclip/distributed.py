@@ -65,8 +65,9 @@ def init_from_env(backend=None, single_rank=False):
 class GradSync:
     """SUM all-reduce of parameter gradients, arena by arena, overlapped with the remaining backward work."""
 
-    def __init__(self, comm, arenas=(), extra_params=()):
+    def __init__(self, comm, arenas=(), extra_params=(), scale=1.0):
         self.comm = comm
+        self.scale = float(scale)           # 1 for the global-batch loss (sum); 1/world for per-rank local losses (mean)
         self.arenas = [a for a in arenas if a is not None]
         self.extra = [p for p in extra_params]
         self.side = torch.cuda.Stream() if torch.cuda.is_available() else None
@@ -78,12 +79,16 @@ class GradSync:
             return
         if self.side is None:
             self.comm.all_reduce_sum(arena.grad)
+            if self.scale != 1.0:
+                arena.grad.mul_(self.scale)
             return
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
             self.comm.all_reduce_sum(arena.grad)
+            if self.scale != 1.0:
+                arena.grad.mul_(self.scale)
             done = torch.cuda.Event()
             done.record()
         self._pending.append(done)
@@ -96,6 +101,8 @@ class GradSync:
         if grads:
             flat = torch.cat([g.reshape(-1) for g in grads])
             self.comm.all_reduce_sum(flat)
+            if self.scale != 1.0:
+                flat.mul_(self.scale)
             off = 0
             for g in grads:
                 g.copy_(flat[off:off + g.numel()].view_as(g))

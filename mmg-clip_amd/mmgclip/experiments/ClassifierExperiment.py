@@ -17,12 +17,19 @@ import torch
 os.environ["TOKENIZERS_PARALLELISM"] = "false"
 
 from ..callbacks.early_stopping import EarlyStopper                      # noqa: E402
+from ..dataset.synthetic import BENIGN_MALIGNANT, MASS_SHAPES            # noqa: E402
 from ..loss.loss_controller import create_loss                           # noqa: E402
 from ..networks.mmgclip_model import MMGCLIP as model, _get              # noqa: E402
+from ..params import begin_step                                          # noqa: E402
 from ..scheduler.warmup_cosine import LinearWarmupCosineAnnealingLR      # noqa: E402
 from ..utils.global_utils import create_directory_if_not_exists         # noqa: E402
 from ..utils.logger import logger                                        # noqa: E402
 from ..utils.train_utils import epoch_time                               # noqa: E402
+
+
+def _label_value(label, enum):
+    """Reference datasets hand labels over as ints or as enum member names (mmgclip/prompts/enums.py)."""
+    return enum[label] if isinstance(label, str) else int(label)
 
 
 class _NullWriter:
@@ -64,10 +71,10 @@ class ClassifierExperiment:
 
         lr, wd = self.config.optimizer.config.learning_rate, self.config.optimizer.config.weight_decay
         if _get(config, "optimizer.config.fused", False):
+            # the towers' parameter arenas do not exist yet (they are built at the first forward): FusedAdamW finds them from
+            # the parameters at every step
             from ..optim import FusedAdamW
-            arenas = [getattr(m, "arena", None) for m in (getattr(self.model, "image_encoder", None), self.model.text_encoder)]
-            self.optimizer = FusedAdamW([p for p in self.model.parameters() if p.requires_grad], lr=lr, weight_decay=wd,
-                                        arenas=arenas)
+            self.optimizer = FusedAdamW([p for p in self.model.parameters() if p.requires_grad], lr=lr, weight_decay=wd)
         else:
             self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=wd)
 
@@ -81,18 +88,49 @@ class ClassifierExperiment:
 
         self.ckp_path = create_directory_if_not_exists(self.config.checkpoints.checkpoints_export_dir)
         self.ckp_path = os.path.join(self.ckp_path, self.config.checkpoints.checkpoints_file_name)
-        self.early_stopper = EarlyStopper(patience=self.config.base.patience, delta=0, trace_func=logger.warning)
-        self.writer = _summary_writer(self.config.base.tensorboard_export_dir)
+        # data-parallel run: every rank takes the same early-stopping decisions (the validation loss is averaged over the
+        # ranks in run()), rank 0 alone writes the checkpoint file and the TensorBoard scalars
+        self._lead = comm is None or comm.rank == 0
+        self.early_stopper = EarlyStopper(patience=self.config.base.patience, delta=0, trace_func=logger.warning, save=self._lead)
+        self.writer = _summary_writer(self.config.base.tensorboard_export_dir) if self._lead else _NullWriter()
+        self._sync = None
+
+    # ---- data parallelism (additive: the reference is single-process) --------------------------------------------
+    def _towers(self):
+        return [t for t in (getattr(self.model, "image_encoder", None), self.model.text_encoder)
+                if t is not None and hasattr(t, "post_backward_hook")]
+
+    def _grad_sync(self):
+        """GradSync over the tower arenas + every other trainable parameter; built once the arenas exist, i.e. after the first
+        forward.  With the global-batch loss the gradients of the ranks are SUMMED (the loss carries 1/(2N) of the global mean);
+        with `distributed.global_loss: false` every rank has its own local-batch loss and the gradients are AVERAGED."""
+        if self._sync is None:
+            from ..distributed import GradSync
+            arenas = [t.arena for t in self._towers() if t.arena is not None and t.arena.any_trainable()]
+            owned = {id(p) for a in arenas for p in a.params}
+            extra = [p for p in self.model.parameters() if p.requires_grad and id(p) not in owned]
+            use_global = _get(self.config, "distributed.global_loss", True)
+            self._sync = GradSync(self.comm, arenas, extra, scale=1.0 if use_global else 1.0 / self.comm.world_size)
+            for t in self._towers():
+                t.post_backward_hook = self._sync.reduce_arena_async
+        return self._sync
 
     def train(self):
         """One epoch; returns the mean of the per-step losses (ClassifierExperiment.py:93-132)."""
         self.model.train()
         loss_list = []
+        parallel = self.comm is not None and self.comm.active
         for index, batch in enumerate(self.train_dataloader):
             self.optimizer.zero_grad(set_to_none=True)
+            if parallel:
+                for t in self._towers():
+                    begin_step(t)
             outputs = self.model(batch)
             loss, labels = self.criterion(**outputs)
+            sync = self._grad_sync() if parallel else None      # (installs the towers' post-backward hooks on first use)
             loss.backward()
+            if sync is not None:
+                sync.finish()                                   # every gradient is the all-rank sum before the optimizer reads it
             self.optimizer.step()
             loss_list.append(loss.item())
         self.scheduler.step()
@@ -140,19 +178,18 @@ class ClassifierExperiment:
                 prompt_emb[name] = head.L2Normalize.apply(te).contiguous()
                 targets[name], preds[name] = [], []
             for batch in self.valid_dataloader:
-                outputs = self.model(batch, validation=True)
-                loss, _ = self.criterion(**{k: v for k, v in outputs.items() if k != "text_embeddings2"}) \
-                    if self.criterion.__class__.__name__ != "MMGCLIPLoss" else create_loss("CLIPLoss")()(**outputs)
+                outputs = self.model(batch)                      # :166 (no `validation` flag: MMGCLIPLoss keeps its second text pass)
+                loss, _ = self.criterion(**outputs)              # :169 the configured criterion, t2t term included
                 loss_list.append(loss.item())
                 labels = batch["prompt_labels"]
                 scale = outputs["logit_scale"].reshape(1).float().contiguous()
                 for name, te in prompt_emb.items():
                     _, _, sims = head.rows_forward(outputs["image_embeddings"].contiguous(), te, scale, 0, True)   # [n,k]
                     preds[name].append(sims.cpu().numpy())
-                    if name == "malig":
-                        targets[name].extend(int(l["BenignMalignantDatasetLabels"]) for l in labels)
-                    elif name == "shapes":
-                        targets[name].extend(int(l["MassShapeLabels"]) for l in labels)
+                    if name == "malig":         # int (exam-report dataset) or the enum member's name (image-label dataset): :179-185
+                        targets[name].extend(_label_value(l["BenignMalignantDatasetLabels"], BENIGN_MALIGNANT) for l in labels)
+                    elif name == "shapes":      # :199-202
+                        targets[name].extend(_label_value(l["MassShapeLabels"], MASS_SHAPES) for l in labels)
                     else:
                         targets[name].extend(-1 if l["BIRADS"] == "unknown" else int(l["BIRADS"]) for l in labels)
         epoch_loss = float(np.mean(loss_list)) if loss_list else float("nan")
@@ -180,6 +217,10 @@ class ClassifierExperiment:
             train_loss = self.train()
             val = self.validate() if self.valid_dataloader is not None else (train_loss, -1, -1, -1, -1)
             val_loss = val[0]
+            if self.comm is not None and self.comm.active:       # same early-stopping decision on every rank
+                t = torch.tensor([float(val_loss)], dtype=torch.float64, device=self.device if self.device.type == "cuda" and
+                                 torch.distributed.get_backend(self.comm.group) == "nccl" else "cpu")
+                val_loss = float(self.comm.all_reduce_sum(t)[0]) / self.comm.world_size
             mins, secs = epoch_time(t0, time.time())
             self.writer.add_scalar('lr', self.optimizer.param_groups[0]['lr'], self.current_epoch + 1)
             self.early_stopper(val_loss, self.current_epoch, self.model, self.optimizer, self.ckp_path)

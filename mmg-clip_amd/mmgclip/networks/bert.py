@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
-from ..params import ParamArena
+from ..params import ParamArena, backward_finished, note_forward
 
 
 class BertConfigLite:
@@ -274,6 +274,7 @@ class BertTower(nn.Module):
         needs_grad = torch.is_grad_enabled() and self._arena.any_trainable()
         use_packed = self.packed if packed is None else bool(packed)
         lens = self._lengths_of(attention_mask) if (use_packed and attention_mask is not None and ids.shape[1] <= 256) else None
+        note_forward(self, needs_grad)
         return _BertFn.apply(self, ids, tt, mask, self._anchor if needs_grad else None, lens)
 
 
@@ -306,8 +307,7 @@ class _BertFn(torch.autograd.Function):
             tower._backward_mb(dh[row:row + B * S], sv)
             row += B * S
         ctx.saved_mb = None
-        if tower.post_backward_hook is not None:
-            tower.post_backward_hook(tower._arena)
+        backward_finished(tower)
         return None, None, None, None, None, None
 
 

@@ -26,7 +26,7 @@ import torch.nn as nn
 from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
-from ..params import ParamArena
+from ..params import ParamArena, backward_finished, note_forward
 
 CONFIGS = {
     "tiny": dict(depths=(3, 3, 9, 3), dims=(96, 192, 384, 768)),
@@ -328,6 +328,7 @@ class ConvNextTower(nn.Module):
         if needs_grad and (images.shape[-2] % 32 or images.shape[-1] % 32):
             raise NotImplementedError("training the ConvNeXt tower needs H and W to be multiples of 32 (inference accepts any "
                                       "size >= 32: strided layers drop the remainder exactly as torch's convolutions do)")
+        note_forward(self, needs_grad)
         return _ConvNextFn.apply(self, images.float().contiguous(), self._anchor if needs_grad else None)
 
 
@@ -364,6 +365,5 @@ class _ConvNextFn(torch.autograd.Function):
             i += n
         tower._finalize_grads(tmp)
         ctx.saved_mb = None
-        if tower.post_backward_hook is not None:
-            tower.post_backward_hook(tower._arena)
+        backward_finished(tower)
         return None, None, None

@@ -17,7 +17,7 @@ import torch.nn as nn
 from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
-from ..params import ParamArena
+from ..params import ParamArena, backward_finished, note_forward
 from .._hip import call, ptr, stream
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -211,6 +211,7 @@ class ResNetTower(nn.Module):
             x = x.view(x.shape[0], 1, 1, x.shape[1]).repeat(1, 3, 1, 1)
         self._materialize(x.device)
         needs_grad = torch.is_grad_enabled() and self.training and self._arena.any_trainable()
+        note_forward(self, needs_grad)
         return _ResNetFn.apply(self, x.float().contiguous(), self._anchor if needs_grad else None)
 
 
@@ -233,6 +234,5 @@ class _ResNetFn(torch.autograd.Function):
         for bi in range(len(blocks) - 1, -1, -1):
             dh = tower._block_bwd(dh, saved[bi], blocks[bi], f"3.{bi}.", need_dx=bi > 0)
         ctx.state = None
-        if tower.post_backward_hook is not None:
-            tower.post_backward_hook(tower._arena)
+        backward_finished(tower)
         return None, None, None

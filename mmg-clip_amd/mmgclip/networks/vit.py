@@ -17,7 +17,7 @@ from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
 from .._hip import call, ptr, stream
-from ..params import ParamArena
+from ..params import ParamArena, backward_finished, note_forward
 
 LN_EPS = 1e-6
 
@@ -187,6 +187,7 @@ class ViTTower(nn.Module):
             raise ValueError(f"ViT was built for {self.image_size}x{self.image_size} inputs (learned positions), got {tuple(images.shape)}")
         self._materialize(images.device)
         needs_grad = torch.is_grad_enabled() and self._arena.any_trainable()
+        note_forward(self, needs_grad)
         return _ViTFn.apply(self, images.float().contiguous(), self._anchor if needs_grad else None)
 
 
@@ -216,6 +217,5 @@ class _ViTFn(torch.autograd.Function):
             tower._backward_mb(dfeat[i:i + sv["B"]].contiguous(), sv)
             i += sv["B"]
         ctx.saved_mb = None
-        if tower.post_backward_hook is not None:
-            tower.post_backward_hook(tower._arena)
+        backward_finished(tower)
         return None, None, None

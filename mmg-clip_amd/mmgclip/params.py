@@ -30,6 +30,7 @@ class ParamArena:
             view = self.data[o:o + p.numel()].view(p.shape)
             view.copy_(p.data.to(device=device, dtype=torch.float32))
             p.data = view
+            p._mmg_arena = self                 # lets an optimizer find the flat buffers from the parameter alone (optim.FusedAdamW)
             self._grad_views[n] = self.grad[o:o + p.numel()].view(p.shape)
         self._by_name = dict(named_params)
         self.manual_version = 0
@@ -87,3 +88,25 @@ class ParamArena:
 
     def any_trainable(self):
         return any(p.requires_grad for p in self.params)
+
+
+# ---- when is a tower's gradient complete? ------------------------------------------------------------------------------------
+# A tower can run several times in one step (MMGCLIPLoss: the text tower encodes the report and the impression,
+# mmgclip/networks/mmgclip_model.py:154-164) and every run has its own autograd backward accumulating into the same arena.
+# `post_backward_hook(arena)` (the gradient all-reduce of distributed.GradSync) must fire after the LAST of them only.
+def note_forward(tower, needs_grad):
+    """Call from the tower's forward: one more backward will arrive if this forward was recorded for autograd."""
+    if needs_grad:
+        tower._open_backwards = getattr(tower, "_open_backwards", 0) + 1
+
+
+def backward_finished(tower):
+    """Call at the end of the tower's autograd backward; fires the hook once no recorded forward is left without its backward."""
+    tower._open_backwards = max(0, getattr(tower, "_open_backwards", 0) - 1)
+    if tower._open_backwards == 0 and tower.post_backward_hook is not None:
+        tower.post_backward_hook(tower._arena)
+
+
+def begin_step(tower):
+    """Forget forwards whose backward never came (e.g. an evaluation pass run with gradients enabled)."""
+    tower._open_backwards = 0

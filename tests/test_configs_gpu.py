@@ -1,0 +1,172 @@
+"""BASELINE configs C4 / C5 at their per-GPU sizes, plus the pieces of them no smaller test reaches.
+
+  * flash attention at S = 4097 (ViT-B/16 on 1024x1024: 64 x 64 patches + class token), all 12 heads, vs fp32 torch;
+  * C4: ViT-B/16, 512 images of 1024x1024 per GPU, gradient-checkpointed: one whole training step through MMGCLIP, and the
+    tower's batch-size independence (512 in one call == two calls of 256 accumulated) - the property tests/test_fullsize_gpu.py
+    uses where the fp32 oracle is too slow to be the checker;
+  * C5: ConvNeXt-B, 1024 images per GPU, e4m3 forward GEMMs + gradient checkpointing: the same two checks;
+  * MMGCLIPLoss gradients against the reference-run fixtures (tests/golden/g2_head_n*.npz: mmg_dimg / mmg_dtxt / mmg_dtxt2 /
+    mmg_dlogit_scale, written by the reference's own MMGCLIPLoss).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CFG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmg-clip_amd", "configs")
+BF = torch.bfloat16
+
+
+def _rel(a, b):
+    a, b = a.detach().float().flatten().double(), b.detach().float().flatten().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_flash_attention_s4097_all_heads(dev):
+    """One image's worth of ViT-B/16 attention at 1024x1024: S = 4097 (ragged last tile: 4097 = 64 * 64 + 1), 12 heads."""
+    from mmgclip import kernels as K
+    B, S, heads = 1, 4097, 12
+    Hd = heads * 64
+    g = torch.Generator().manual_seed(4097)
+    qkv = torch.randn(B * S, 3 * Hd, generator=g).to(dev).to(BF)
+    ctx, lse = K.attention_fwd(qkv, None, B, S, heads)
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = (t.view(B, S, heads, 64).permute(0, 2, 1, 3) for t in qr.chunk(3, dim=-1))
+    p = (q @ k.transpose(-1, -2) / 8.0).softmax(-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B * S, Hd)
+    assert _rel(ctx, ref) < 1e-2
+    ref_lse = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) / 8.0, -1)            # [B, heads, S]
+    got_lse = lse.float().reshape(-1)
+    assert got_lse.numel() == ref_lse.numel()
+    # the kernel may keep the LSE in the exp2 domain and in its own (b, head, row) order: compare as sorted multisets of nats
+    cand = [got_lse, got_lse * math.log(2.0)]
+    assert min(_rel(c.sort().values, ref_lse.reshape(-1).sort().values) for c in cand) < 1e-3
+    dctx = torch.randn(B * S, Hd, generator=g).to(dev).to(BF)
+    dqkv = K.attention_bwd(qkv, None, ctx, lse, dctx, B, S, heads)
+    ref.backward(dctx.float())
+    assert _rel(dqkv, qr.grad) < 2e-2
+    # every row written (an unvalidated rows-per-wave knob left rows untouched): no row of the output may be all zero
+    assert (ctx.float().abs().sum(-1) > 0).all() and (dqkv.float().abs().sum(-1) > 0).all()
+
+
+def test_attention_rows_per_wave_knob_is_validated(dev, monkeypatch):
+    """MMG_ATT_RB outside {1, 2, 4} must not leave rows unwritten (it used to launch RB = 1 on a grid sized for the env value)."""
+    from mmgclip import kernels as K
+    B, S, heads = 1, 700, 2
+    qkv = torch.randn(B * S, 3 * heads * 64, generator=torch.Generator().manual_seed(7)).to(dev).to(BF)
+    monkeypatch.setenv("MMG_ATT_RB", "4")
+    want, _ = K.attention_fwd(qkv, None, B, S, heads, force_long=True)
+    for bad in ("3", "8", "0", "x"):
+        monkeypatch.setenv("MMG_ATT_RB", bad)
+        got, _ = K.attention_fwd(qkv, None, B, S, heads, force_long=True)
+        assert _rel(got, want) < 1e-2, bad
+
+
+def _cfg(name, *over):
+    from mmgclip.config import compose
+    return compose(CFG_DIR, name, list(over))
+
+
+def _tower_split_equality(make_tower, n, image_size, feat_dim, dev, tol_feat, tol_grad):
+    """features / parameter gradients of n images in ONE call == two calls of n/2 with gradients accumulated."""
+    g = torch.Generator().manual_seed(n)
+    img = torch.rand(n, 1, image_size, image_size, generator=g).to(dev)
+    wgt = torch.randn(n, feat_dim, generator=g).to(dev)
+    tower = make_tower().to(dev)
+    feat = tower(img)
+    (feat * wgt).sum().backward()
+    assert torch.isfinite(feat).all() and feat.shape == (n, feat_dim)
+    whole_f = feat.detach().clone()
+    whole_g = {k: p.grad.detach().clone() for k, p in tower.model.named_parameters()}
+    del feat
+    for p in tower.parameters():
+        p.grad = None
+    h = n // 2
+    halves = []
+    for s in (slice(0, h), slice(h, n)):
+        f = tower(img[s].contiguous())
+        (f * wgt[s]).sum().backward()
+        halves.append(f.detach().clone())
+    assert _rel(torch.cat(halves), whole_f) < tol_feat
+    worst = max((_rel(p.grad, whole_g[k]), k) for k, p in tower.model.named_parameters())
+    assert worst[0] < tol_grad, worst
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    del tower
+    torch.cuda.empty_cache()
+    return peak
+
+
+def test_c4_vit_b16_512_per_gpu_checkpointed(dev):
+    """BASELINE C4 per-GPU share: 512 images of 1024x1024 through ViT-B/16 (S = 4097) with gradient checkpointing."""
+    from mmgclip.networks.encoder import ViTB16Encoder
+    torch.manual_seed(0)
+    peak = _tower_split_equality(lambda: ViTB16Encoder(image_size=1024, micro_batch=64, checkpoint=True), 512, 1024, 768, dev, 1e-5, 5e-3)
+    assert peak < 200, peak          # fits the 288 GB part with room for BERT, optimizer state and the 2 GiB of pixels
+
+
+def test_c5_convnext_base_1024_per_gpu_fp8_checkpointed(dev):
+    """BASELINE C5 per-GPU share: 1024 images of 1024x1024 through ConvNeXt-B with e4m3 forward GEMMs + gradient checkpointing."""
+    from mmgclip.networks.encoder import ConvNextBaseEncoder
+    torch.manual_seed(0)
+    peak = _tower_split_equality(lambda: ConvNextBaseEncoder(micro_batch=64, checkpoint=True, fp8=True), 1024, 1024, 1024, dev, 1e-5, 5e-3)
+    assert peak < 200, peak
+
+
+@pytest.mark.parametrize("name,net,batch,extra", [
+    ("train_exam_reports_clf", "clip_vitb16_bert_pixels", 512, []),
+    ("train_multi_class_clf", "clip_convnextbase_bert_pixels", 1024, ["networks.image_encoder.fp8=true"])])
+def test_c4_c5_whole_step_at_per_gpu_batch(dev, name, net, batch, extra):
+    """One optimizer step of the named BASELINE config at its per-GPU batch: loss finite and ~ ln(batch) at initialisation
+    (all images alike to an untrained tower), every trainable parameter gets a finite gradient, the step moves the weights."""
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    from mmgclip.optim import FusedAdamW
+    torch.manual_seed(0)
+    cfg = _cfg(name, f"networks={net}", "tokenizer=bert_clinical_seqlen=77", "networks/dropout=dropout0",
+               "networks.image_encoder.micro_batch=64", "networks.image_encoder.image_size=1024",
+               "networks.image_encoder.checkpoint=true", *extra)
+    model = MMGCLIP(cfg).train()
+    b = synthetic_batch(batch, S=77, image_size=1024, seed=42)
+    b["image"] = b["image"].to(dev)
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
+    before = model.image_projection_layer.layers[0].weight.detach().clone() if hasattr(model.image_projection_layer, "layers") \
+        else model.image_projection_layer.layer.weight.detach().clone()
+    loss, labels = create_loss(cfg.loss.config.loss_name)()(**model(b, materialize_logits=False))
+    loss.backward()
+    assert math.isfinite(loss.item()) and abs(loss.item() - math.log(batch)) < 0.5, loss.item()
+    assert labels.shape == (batch,)
+    bad = [n for n, p in model.named_parameters() if p.requires_grad and (p.grad is None or not torch.isfinite(p.grad).all())]
+    assert not bad, bad[:5]
+    stem = dict(model.image_encoder.model.named_parameters())
+    first = next(iter(stem.values())).detach().clone()
+    opt.step()
+    after = model.image_projection_layer.layers[0].weight if hasattr(model.image_projection_layer, "layers") \
+        else model.image_projection_layer.layer.weight
+    assert not torch.equal(before, after.detach())
+    assert not torch.equal(first, next(iter(stem.values())).detach())
+    # the forward AFTER the step must see the updated tower weights (working copies refreshed)
+    loss2, _ = create_loss(cfg.loss.config.loss_name)()(**model(b, materialize_logits=False))
+    assert math.isfinite(loss2.item()) and loss2.item() != loss.item()
+
+
+@pytest.mark.parametrize("n", [8, 32, 37, 256])
+def test_mmgclip_loss_gradients_match_reference_golden(dev, golden_dir, n):
+    """MMGCLIPLoss forward AND backward vs the reference's own class (fixtures written by tests/golden/make_golden.py)."""
+    from mmgclip import head
+    from mmgclip.loss.loss_controller import create_loss
+    g = np.load(os.path.join(golden_dir, f"g2_head_n{n}.npz"))
+    t = lambda k: torch.from_numpy(g[k]).to(dev).requires_grad_(True)          # noqa: E731
+    img, txt, txt2, ls = t("img"), t("txt"), t("txt2"), t("logit_scale_param")
+    ie, te, te2 = head.L2Normalize.apply(img), head.L2Normalize.apply(txt), head.L2Normalize.apply(txt2)
+    loss, labels = create_loss("MMGCLIPLoss")()(image_embeddings=ie, text_embeddings=te, text_embeddings2=te2, logit_scale=ls.exp())
+    assert abs(loss.item() - float(g["mmg_loss"])) < 5e-6 * abs(float(g["mmg_loss"]))
+    loss.backward()
+    for got, key in ((img.grad, "mmg_dimg"), (txt.grad, "mmg_dtxt"), (txt2.grad, "mmg_dtxt2")):
+        want = g[key]
+        err = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+        assert err < 2e-4, (key, err)
+    assert abs(ls.grad.item() - float(g["mmg_dlogit_scale"])) < 2e-4 * max(abs(float(g["mmg_dlogit_scale"])), 1e-3)
