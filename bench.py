@@ -33,6 +33,9 @@ import torch.distributed as dist              # noqa: E402
 GFLOP_PER_PAIR = {  # fwd+bwd, 2 FLOP/MAC, train = 3 x forward
     ("tiny", 1024, 77): 557.4 + 39.9, ("tiny", 224, 77): 26.7 + 39.9, ("base", 1024, 77): 1923.6 + 39.9,
     ("vit_b16", 1024, 77): 3949.0 + 39.9, ("vit_b16", 224, 77): 105.4 + 39.9,
+    ("tiny", 1024, 256): 557.4 + 137.7, ("tiny", 224, 256): 26.7 + 137.7,
+    # reference-faithful mode: frozen BERT forward only + the two projections (last paragraph)
+    ("faithful", 77): 13.3, ("faithful", 256): 45.9,
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
@@ -44,17 +47,25 @@ def build(args, comm):
     from mmgclip.optim import FusedAdamW
     from mmgclip.utils.global_utils import seeding
     net = {"tiny": "clip_convnexttiny_bert_pixels", "base": "clip_convnextbase_bert_pixels",
-           "vit_b16": "clip_vitb16_bert_pixels"}[args.variant]
-    cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf", [
-        f"networks={net}", f"tokenizer=bert_clinical_seqlen={args.seq_len}", "networks/dropout=dropout0",
-        f"networks.image_encoder.micro_batch={args.micro_batch}", f"networks.image_encoder.image_size={args.image_size}",
-        "optimizer.config.fused=true"] + (["networks.image_encoder.checkpoint=true"] if args.checkpoint else [])
-        + (["networks.image_encoder.fp8=true"] if args.fp8 and args.variant != "vit_b16" else []))
+           "vit_b16": "clip_vitb16_bert_pixels", "faithful": "clip_convnext_bert"}[args.variant]
+    tok = "bert_clinical" if args.seq_len == 256 else f"bert_clinical_seqlen={args.seq_len}"     # 256 = the reference's default file
+    over = [f"networks={net}", f"tokenizer={tok}", "networks/dropout=dropout0", "optimizer.config.fused=true"]
+    if args.variant == "faithful":
+        # what the reference's step really computes: pre-extracted [n,1,768,1,1] features pass through, BERT is
+        # frozen (forward only), the two 768->512 linears are the only trainable weights
+        over += ["networks.text_encoder.random_init=true"]
+    else:
+        over += [f"networks.image_encoder.micro_batch={args.micro_batch}", f"networks.image_encoder.image_size={args.image_size}"]
+        over += ["networks.image_encoder.checkpoint=true"] if args.checkpoint else []
+        over += ["networks.image_encoder.fp8=true"] if args.fp8 and args.variant != "vit_b16" else []
+    cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf", over)
+    assert cfg.tokenizer.config.sequence_length == args.seq_len
     seeding(cfg.base.seed)
     model = MMGCLIP(cfg)
     model.train()
     criterion = create_loss(cfg.loss.config.loss_name)(comm=comm)
-    arenas = lambda: [model.image_encoder.arena, model.text_encoder.arena]      # noqa: E731
+    arenas = lambda: [a for a in (getattr(getattr(model, "image_encoder", None), "arena", None), model.text_encoder.arena)   # noqa: E731
+                      if a is not None and a.any_trainable()]
     return cfg, model, criterion, arenas
 
 
@@ -68,8 +79,8 @@ def _host_cores():
 
 def cpu_baseline_worker(seconds_budget):
     """Oracle training step (ConvNeXt-T + BERT-base + projection + CLIPLoss + AdamW, fp32) on the host cores; prints JSON.
-    `value` is measured on a bounded sample of the benchmarked workload itself (C2 shapes: 1024x1024 images, 77-token prompts,
-    4 pairs per step); the reference's own CPU-runnable configuration C1 (8 pairs of 224x224) is reported beside it."""
+    `value` is BASELINE.md §4's prescription: config C1 (8 pairs of 224x224, S=77), the reference's own CPU-runnable case;
+    a bounded sample of the benchmarked workload itself (C2 shapes: 1024x1024 images, 4 pairs per step) is reported beside it."""
     from mmgclip.dataset.synthetic import synthetic_batch
     from mmgclip.networks.bert import BertConfigLite, _hf_layout
     from mmgclip.networks.convnext import build_features
@@ -113,11 +124,11 @@ def cpu_baseline_worker(seconds_budget):
     med1, k1 = measure(8, 224, 0.3 * seconds_budget, 12)
     med2, k2 = measure(n2, 1024, 0.7 * seconds_budget, 4)
     print(json.dumps({
-        "value": round(n2 / med2, 3), "unit": "image-text pairs/sec", "cores": cores, "kind": "port",
-        "sample": f"oracle fp32 training step (ConvNeXt-T + BERT-base, fwd+bwd+AdamW) on {n2} pairs of the C2 workload "
-                  f"(1024x1024 images, S=77): median of {k2} step(s) after one warm-up, {med2:.2f} s/step",
-        "c1": {"value": round(8 / med1, 3), "sample": f"BASELINE config C1 (n=8, 224x224, S=77): median of {k1} step(s), "
-                                                      f"{med1 * 1000:.0f} ms/step"}}), flush=True)
+        "value": round(8 / med1, 3), "unit": "image-text pairs/sec", "cores": cores, "kind": "port",
+        "sample": f"BASELINE config C1, the reference's own CPU-runnable case (BASELINE.md §4): oracle fp32 training step (ConvNeXt-T + "
+                  f"BERT-base, fwd+bwd+AdamW), n=8, 224x224, S=77: median of {k1} step(s) after one warm-up, {med1 * 1000:.0f} ms/step",
+        "c2_sample": {"value": round(n2 / med2, 3), "sample": f"{n2} pairs of the benchmarked C2 workload (1024x1024 images, S=77): median of "
+                                                               f"{k2} step(s) after one warm-up, {med2:.2f} s/step"}}), flush=True)
 
 
 def cpu_baseline(seconds_budget=30.0, hard_timeout=240.0):
@@ -146,8 +157,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=77)
     ap.add_argument("--micro-batch", type=int, default=None,
                     help="images per pass through the image tower; default 256 (= one pass) for ConvNeXt-T and ViT-B/16, 64 for ConvNeXt-B and with --checkpoint")
-    ap.add_argument("--variant", default="tiny", choices=["tiny", "base", "vit_b16"],
-                    help="image tower: ConvNeXt-T (headline C2), ConvNeXt-B (C5 shape, bf16), ViT-B/16 (C4 shape)")
+    ap.add_argument("--variant", default="tiny", choices=["tiny", "base", "vit_b16", "faithful"],
+                    help="image tower: ConvNeXt-T (headline C2), ConvNeXt-B (C5 shape, bf16), ViT-B/16 (C4 shape); faithful = the "
+                         "reference's own step (pre-extracted 768-d features, frozen BERT forward, two trainable projections)")
     ap.add_argument("--checkpoint", action="store_true", help="gradient checkpointing of the image tower (micro-batch granularity)")
     ap.add_argument("--fp8", action="store_true", help="ConvNeXt blocks with C >= 512: forward pointwise GEMMs on e4m3 MFMA (config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,8 +195,9 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg, model, criterion, arenas = build(args, comm)
-    batch = synthetic_batch(args.batch, S=args.seq_len, image_size=args.image_size, seed=42 + rank)
-    batch["image"] = batch["image"].to(dev)
+    batch = synthetic_batch(args.batch, S=args.seq_len, image_size=None if args.variant == "faithful" else args.image_size, seed=42 + rank)
+    key = "image_features" if args.variant == "faithful" else "image"
+    batch[key] = batch[key].to(dev)
     batch["text_tokens"] = batch["text_tokens"].to(dev)
     torch.cuda.synchronize()
 
@@ -201,13 +214,14 @@ def main():
         if sync is None:                      # arenas exist after the first forward
             sync = distributed.GradSync(comm, arenas(), extra)
             if comm is not None:
-                model.image_encoder.post_backward_hook = sync.reduce_arena_async
-                model.text_encoder.post_backward_hook = sync.reduce_arena_async
+                for tower in (getattr(model, "image_encoder", None), model.text_encoder):
+                    if tower is not None:
+                        tower.post_backward_hook = sync.reduce_arena_async
         loss.backward()
         sync.finish()
         if optimizer is None:
             optimizer = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.optimizer.config.learning_rate,
-                                   weight_decay=cfg.optimizer.config.weight_decay, arenas=arenas())
+                                   weight_decay=cfg.optimizer.config.weight_decay)
         optimizer.step()
         return loss
 
@@ -238,16 +252,18 @@ def main():
     ms_per_step = elapsed / args.steps * 1000.0
     pairs = args.batch * world * args.steps
     value = pairs / elapsed
-    gflop = GFLOP_PER_PAIR.get((args.variant, args.image_size, args.seq_len))
+    gflop = GFLOP_PER_PAIR.get(("faithful", args.seq_len) if args.variant == "faithful" else (args.variant, args.image_size, args.seq_len))
     out = {
         "metric": "image-text pairs/sec (global batch)", "value": round(value, 2), "unit": "image-text pairs/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 (fp8 e4m3 forward GEMMs in the C >= 512 ConvNeXt blocks)" if args.fp8 and args.variant != "vit_b16" else "bf16",
         "data": "synthetic",
-        "config": {"workload": f"{'C2' if args.variant == 'tiny' else 'C4-shape' if args.variant == 'vit_b16' else 'C5-shape'}: train_binary_class_clf, "
-                               f"{'ViT-B/16' if args.variant == 'vit_b16' else 'ConvNeXt-' + args.variant} {args.image_size}x{args.image_size}x1 + BERT-base "
-                               f"S={args.seq_len}, LinearProjection 768->512, CLIPLoss, AdamW, all parameters trained",
+        "config": {"workload": (f"reference-faithful: train_binary_class_clf, pre-extracted 768-d image features + frozen BERT-base S={args.seq_len} "
+                                f"(forward only), LinearProjection 768->512 x2 trained, CLIPLoss, AdamW") if args.variant == "faithful" else
+                               (f"{'C2' if args.variant == 'tiny' else 'C4-shape' if args.variant == 'vit_b16' else 'C5-shape'}: train_binary_class_clf, "
+                                f"{'ViT-B/16' if args.variant == 'vit_b16' else 'ConvNeXt-' + args.variant} {args.image_size}x{args.image_size}x1 + BERT-base "
+                                f"S={args.seq_len}, LinearProjection 768->512, CLIPLoss, AdamW, all parameters trained"),
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "micro_batch": args.micro_batch,
                    "parallelism": f"dp{world}", "loss_scope": "global (all-gather)" if world > 1 else "local",
                    "algorithmic_gflop_per_pair": gflop,
@@ -271,7 +287,10 @@ def main():
                 r = linalg.PROFILE.roofline(fam, st)
                 if fam in traffic:
                     r["traffic"] = round(traffic[fam]["hbm_bytes_per_launch"])
-                    r["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile[-1]
+                    r["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)"
+                    # the PMC counters cannot be read from inside the process: this figure is STATIC, from the committed rocprofv3
+                    # passes of this same command, not measured in this run
+                    r["traffic_source"] = "static: profiles/%s (rocprofv3 --pmc passes of this command, tools/collect_traffic.sh)" % tfile[-1]
                 lines.append(r)
             if lines:
                 out["roofline"] = lines[0]                 # the kernel with the largest share of the timed region

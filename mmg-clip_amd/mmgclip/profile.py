@@ -45,18 +45,24 @@ class KernelProfile:
         return dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms"]))
 
     def roofline(self, family, stats):
-        """The bench.py `roofline` object for one family: the bound is whichever peak the launch sits closer to."""
+        """The bench.py `roofline` object for one family.  The bound is decided by the family's ALGORITHMIC arithmetic intensity
+        (FLOP per byte over all its launches) against the ridge point peak_FLOP/s / peak_B/s (312.5 FLOP/B for bf16 MFMA, 625 for
+        e4m3): above the ridge the matrix cores are the roof, below it HBM is - not by whichever fraction happens to read larger.
+        Both fractions are reported either way."""
         peak = MFMA_FP8_PEAK_TFLOPS if "fp8" in family else MFMA_BF16_PEAK_TFLOPS
         f_mfma = stats["tflops"] / peak
         f_hbm = stats["gbytes_per_s"] / HBM_PEAK_GBS
-        if f_mfma >= f_hbm:
+        intensity = stats["algorithmic_flop_per_launch"] / max(stats["algorithmic_bytes_per_launch"], 1)
+        ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if intensity >= ridge:
             r = {"bound": "mfma", "achieved": stats["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(f_mfma, 4)}
         else:
             r = {"bound": "hbm", "achieved": stats["gbytes_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}
         r.update({"kernel": family, "traffic": None, "launches": stats["launches"], "avg_launch_us": stats["avg_launch_us"],
                   "total_ms": stats["total_ms"], "algorithmic_bytes_per_launch": stats["algorithmic_bytes_per_launch"],
                   "algorithmic_flop_per_launch": stats["algorithmic_flop_per_launch"],
-                  "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4)})
+                  "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4),
+                  "arithmetic_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1)})
         return r
 
 

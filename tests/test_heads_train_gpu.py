@@ -146,3 +146,59 @@ def test_validation_prompt_scores_match_oracle(dev, monkeypatch):
     ref = (1 / 0.07) * ie_ref @ te_ref.t()
     np.testing.assert_allclose(sims.cpu().numpy(), ref.numpy(), atol=0.2)      # bf16 towers/heads; |logit| <= 14.3
     assert sims.shape == (16, 4)
+
+
+@pytest.mark.parametrize("key,classes", [("BenignMalignantDatasetLabels", {"benign": 0, "malignant": 1}),
+                                         ("MassShapeLabels", {"unknown": 0, "oval": 1, "round": 2, "irregular": 3})])
+def test_evaluator_zeroshot_label_prompt_matches_oracle(dev, monkeypatch, key, classes):
+    """Evaluator.zeroshot_label_prompt (evaluator.py:321-478): prompts encoded once, [n,512]x[512,k] scoring kernel, sklearn on the
+    host - against the oracle's restatement fed with the oracle's own embeddings of the same model."""
+    from mmgclip.config import compose
+    from mmgclip.dataset.synthetic import synthetic_batch, synthetic_prompt_tokens
+    from mmgclip.evaluator import Evaluator, label_prompts
+    from mmgclip.networks import bert
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    from oracle import clip_oracle as O
+    from oracle import encoders_oracle as E
+    orig = bert.BertConfigLite.__init__
+
+    def small(self, **kw):
+        kw.setdefault("num_hidden_layers", 2)
+        kw.setdefault("vocab_size", 3000)
+        orig(self, **kw)
+    monkeypatch.setattr(bert.BertConfigLite, "__init__", small)
+    cfg_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmg-clip_amd", "configs")
+    cfg = compose(cfg_dir, "train_binary_class_clf", ["networks.text_encoder.random_init=true", "tokenizer=bert_clinical_seqlen=77"])
+    torch.manual_seed(0)
+    model = MMGCLIP(cfg).eval()
+    ev = Evaluator(cfg, test_dataloader=None, tokenizer=None, model=model)
+    batch = synthetic_batch(96, S=77, vocab_size=3000, seed=33)
+    names = list(classes)
+    g = torch.Generator().manual_seed(1)
+    y = torch.randint(0, len(names), (96,), generator=g).numpy()
+    label_names = [{key: names[i]} for i in y]
+    img_emb = ev.encode_image(batch)
+    assert img_emb.shape == (96, 512) and isinstance(img_emb, np.ndarray)
+    np.random.seed(7)
+    res = ev.zeroshot_label_prompt(img_emb, label_names, classes, key, n_iterations=40)
+    # oracle: fp32 embeddings of the same weights, same prompts (hashed stand-in ids), same metric code path
+    prompts = label_prompts(key, classes)
+    ptok = synthetic_prompt_tokens(prompts, 77, 3000)
+    sd = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+    bsd = {k[len("text_encoder.model."):]: v for k, v in sd.items() if k.startswith("text_encoder.model.")}
+    tf = O.eos_pool(E.bert_forward(bsd, ptok["input_ids"], ptok["attention_mask"], ptok["token_type_ids"]), ptok["attention_mask"])
+    te = O.l2_normalize(O.linear_projection(tf, sd["text_projection_layer.layer.weight"])).numpy()
+    ie = O.l2_normalize(O.linear_projection(batch["image_features"].cpu().flatten(1), sd["image_projection_layer.layer.weight"])).numpy()
+    np.testing.assert_allclose(img_emb, ie, atol=2e-3)
+    np.random.seed(7)
+    per, ci, acc, f1 = O.zeroshot_label_prompt(ie, te, 1 / 0.07, y, n_iterations=40)
+    assert set(res) == set(prompts) | {"accuracy", "f1score"} | ({"auc_ci_mean", "auc_ci_lower", "auc_ci_higher"} if len(prompts) == 2 else set())
+    for i, pr in enumerate(prompts):
+        assert abs(res[pr]["auc"] - per[i][0]) < 0.03 and abs(res[pr]["accuracy"] - per[i][1]) < 0.05, (pr, res[pr], per[i])
+    assert abs(res["accuracy"] - acc) < 0.05 and abs(res["f1score"] - f1) < 0.06
+    if ci is not None:
+        assert abs(res["auc_ci_mean"] - ci[0]) < 0.03 and res["auc_ci_lower"] <= res["auc_ci_mean"] <= res["auc_ci_higher"]
+    # the scoring kernel itself, tightly: same embeddings in, logits out
+    sims = ev.prompt_similarities(ie, prompts)
+    te_dev = ev.encode_text(prompts)
+    np.testing.assert_allclose(sims, (1 / 0.07) * ie @ te_dev.T, atol=2e-4)

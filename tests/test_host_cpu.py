@@ -104,3 +104,27 @@ def test_committed_bench_line_follows_the_driver_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == b["unit"]
+
+
+def test_label_prompt_sentences_and_oracle_scoring():
+    """evaluator.py:329-345 prompt sentences (enum names through process_class_list's wording map, data_utils.py:921-960) and the
+    oracle's restatement of the scoring on a separable toy problem."""
+    import numpy as np
+    from mmgclip.evaluator import label_prompts, process_class_list
+    from oracle import clip_oracle as O
+    margins = {"unknown": 0, "circumscribed": 1, "obscured": 2, "spiculated": 3, "illdefined": 4}      # prompts/enums.py:38-43
+    assert label_prompts("MassMarginLabels", margins) == ["Mass margin is unknown.", "Mass margin is circumscribed.", "Mass margin is obscured.",
+                                                          "Mass margin is spiculated.", "Mass margin is ill defined."]
+    assert label_prompts("BenignMalignantDatasetLabels", {"benign": 0, "malignant": 1}) == ["Finding suggesting benign.", "Finding suggesting malignant."]
+    assert label_prompts("HasMassLabels", {"nomass": 0, "mass": 1}) == ["No mass was observed.", "Findings revealed a mass."]
+    assert process_class_list(["nomass", "oval", "hascalcification"]) == ["no mass", "oval", "has calcification"]
+    with pytest.raises(ValueError):
+        process_class_list("oval")
+    rng = np.random.default_rng(0)
+    te = np.eye(2, 16, dtype=np.float32)
+    y = rng.integers(0, 2, 64)
+    ie = te[y] + 0.05 * rng.standard_normal((64, 16)).astype(np.float32)
+    ie /= np.linalg.norm(ie, axis=1, keepdims=True)
+    np.random.seed(0)
+    per, ci, acc, f1 = O.zeroshot_label_prompt(ie, te, 1 / 0.07, y, n_iterations=50)
+    assert acc == 1.0 and f1 == 1.0 and all(a == 1.0 for a, _ in per) and ci == (1.0, 1.0, 1.0)
