@@ -17,7 +17,8 @@
 //     consecutive row positions of the weight tile: bias + GELU are applied in place and two such tiles ARE the B operand
 //     of GEMM 2's 16x16x32 step - no LDS round trip for the hidden row.  The packing places the hidden units (and the output
 //     columns) so that a lane's pair of tiles is 8 consecutive units: every global access of the kernels is 16 bytes.
-// The bound is the fp32 VALU (erf-GELU, ~15 instructions per hidden element = 3x the MFMA time at C=96), then HBM; the
+// The bound is the fp32 VALU (erf-GELU: the 11-operation polynomial form of common.h, gelu_bf16 - its result is rounded to bf16
+// right away; still ~2x the MFMA time at C=96), then HBM; the
 // backward (cnblock_mlp_bwd_kernel below) recomputes the hidden row and is bound by its 4C-wide stores.
 #include "common.h"
 #include <stdlib.h>
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
                         }
                     }
                     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-                    gf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{pack2bf(gelu_f(h0[0]), gelu_f(h0[1])), pack2bf(gelu_f(h0[2]), gelu_f(h0[3])),
-                                                                 pack2bf(gelu_f(h1[0]), gelu_f(h1[1])), pack2bf(gelu_f(h1[2]), gelu_f(h1[3]))}));
+                    gf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{pack2bf(gelu_bf16(h0[0]), gelu_bf16(h0[1])), pack2bf(gelu_bf16(h0[2]), gelu_bf16(h0[3])),
+                                                                 pack2bf(gelu_bf16(h1[0]), gelu_bf16(h1[1])), pack2bf(gelu_bf16(h1[2]), gelu_bf16(h1[3]))}));
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float dg;
-                            gelu_both(hacc[mi][tt][e], a[e], dg);
+                            gelu_bf16_both(hacc[mi][tt][e], a[e], dg);
                             d[e] = gacc[mi][tt][e] * dg;
                         }
                         gp[2 * tt] = pack2bf(a[0], a[1]); gp[2 * tt + 1] = pack2bf(a[2], a[3]);

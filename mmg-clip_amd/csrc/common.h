@@ -117,6 +117,44 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
     pdf = 0.3989422804014327f * e;
 }
 
+// erf-GELU where the result is ROUNDED TO BF16 (fused CNBlock MLP, bf16 GEMM epilogues): a polynomial with no transcendental
+// for the activation and one for its derivative.  Measured issue cost on gfx950 (tools/micro/valu_rate2.hip, >= 2 waves per SIMD):
+// v_exp_f32 / v_rcp_f32 = 3.4 x a v_fma_f32, so gelu_f above costs 11 + 2 * 3.4 = 17.8 fma-slots and this form 11; gelu_both
+// 22.8 against 18.4.  (Packed forms do not help: v_pk_fma_f32 = 3.9 slots per 2 elements, v_pk_fma_f16 = 1.65.)
+//     xc = clamp(x, -4, 4),  u = xc^2,  t = 0.5 + xc R(u) ~ Phi(x)  (R(16) * 4 = 0.5 exactly: t = 0 / 1 beyond the clamp)
+//     GELU(x) = x t,   GELU'(x) = t + xc phi(xc),  phi(xc) = 2^(-u log2(e) / 2) / sqrt(2 pi)
+// R: degree 7 in u, fitted by tools/fit_gelu.py.  Error of the fp32 evaluation over [-12, 12] against the exact function:
+// relative <= 4.3e-4 (2^-11) for x > 0, absolute <= 1.7e-4 for x < 0 (where |GELU| <= 0.17) - a bf16 result has a relative
+// rounding error of up to 2^-8 = 3.9e-3; GELU' absolute <= 5.4e-4.  fp32 outputs keep gelu_f / gelu_grad_f (1.5e-7).
+__device__ __forceinline__ float gelu_bf16_t(float x, float& xc, float& u) {
+    xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+    u = xc * xc;
+    float r = fmaf(-3.6202913771e-10f, u, 4.5281571812e-08f);
+    r = fmaf(r, u, -2.1615280625e-06f);
+    r = fmaf(r, u, 5.5186495382e-05f);
+    r = fmaf(r, u, -8.6428084215e-04f);
+    r = fmaf(r, u, 8.9540615968e-03f);
+    r = fmaf(r, u, -6.4865888188e-02f);
+    r = fmaf(r, u, 3.9801598429e-01f);      // (nudged so that the fp32 chain gives R(16) = 0.125 exactly)
+    return fmaf(xc, r, 0.5f);
+}
+__device__ __forceinline__ float gelu_bf16(float x) {
+    float xc, u;
+    return x * gelu_bf16_t(x, xc, u);
+}
+__device__ __forceinline__ void gelu_bf16_both(float x, float& g, float& dg) {
+    float xc, u;
+    const float t = gelu_bf16_t(x, xc, u);
+    g = x * t;
+    const float e = __builtin_amdgcn_exp2f(u * -0.72134752044448170f);      // exp(-xc^2 / 2)
+    dg = fmaf(xc * e, 0.3989422804014327f, t);
+}
+__device__ __forceinline__ float gelu_bf16_grad(float x) {
+    float g, dg;
+    gelu_bf16_both(x, g, dg);
+    return dg;
+}
+
 // 16-byte store that bypasses L2 allocation when `nt` (streaming outputs larger than the Infinity Cache)
 __device__ __forceinline__ void store16_stream(void* dst, const uint4 v, bool nt) {
     if (nt) {

@@ -110,7 +110,8 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
             store16(g.aux_out + (size_t)gr * g.ldao + gc, o, g.nt_store);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
+        for (int e = 0; e < 8; ++e)      // bf16 / e4m3 results take the polynomial form (common.h), fp32 results the 1.5e-7 one
+            v[e] = (g.epi == EPI_GELU) ? (g.out_f32 ? gelu_f(v[e]) : gelu_bf16(v[e])) : fmaxf(v[e], 0.f);
     } else if (want_aux) {
         const unsigned hw[4] = {aux.x, aux.y, aux.z, aux.w};
         unsigned act[4];
@@ -121,8 +122,8 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
                 // the activation itself (needed by the weight-gradient GEMM of the same layer) shares cdf/pdf with
                 // its derivative: emitting it here replaces a separate read-modify-write pass over the [M,N] tensor
                 float a0, d0, a1, d1;
-                gelu_both(h0, a0, d0);
-                gelu_both(h1, a1, d1);
+                if (g.out_f32) { gelu_both(h0, a0, d0); gelu_both(h1, a1, d1); }
+                else { gelu_bf16_both(h0, a0, d0); gelu_bf16_both(h1, a1, d1); }
                 v[2 * e] *= d0;
                 v[2 * e + 1] *= d1;
                 act[e] = pack2bf(a0, a1);

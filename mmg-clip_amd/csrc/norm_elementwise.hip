@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict_
         float f[8];
         unpack8(reinterpret_cast<const uint4*>(x)[i], f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = gelu_f(f[e]);
+        for (int e = 0; e < 8; ++e) f[e] = gelu_bf16(f[e]);
         reinterpret_cast<uint4*>(y)[i] = pack8(f);
     }
 }
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void act_grad_kernel(const bf16_t* __restrict_
         unpack8(reinterpret_cast<const uint4*>(dy)[i], g);
         unpack8(reinterpret_cast<const uint4*>(pre)[i], h);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = kind == 0 ? g[e] * gelu_grad_f(h[e]) : (h[e] > 0.f ? g[e] : 0.f);
+        for (int e = 0; e < 8; ++e) g[e] = kind == 0 ? g[e] * gelu_bf16_grad(h[e]) : (h[e] > 0.f ? g[e] : 0.f);
         reinterpret_cast<uint4*>(out)[i] = pack8(g);
     }
 }

@@ -400,3 +400,32 @@ def test_cnblock_fp8_forward_one_block(dev, M, C):
     assert rel(hpre, hpre_o) < 4e-3                         # bf16 storage of the side output
     assert rel(y, y_o) < 6e-3, rel(y, y_o)                  # bf16 storage + the rare rounding-boundary element
     assert rel(y, y_32) > 4 * rel(y, y_o)                   # ... while e4m3 itself moves the block by several times that
+
+
+def test_polynomial_gelu_over_every_bf16_input(dev):
+    """csrc/common.h gelu_bf16 / gelu_bf16_grad (the forms used wherever the result is rounded to bf16): EVERY finite bf16 input,
+    against erf-GELU in fp64.  Stated bars: relative 2^-11 for x > 0, absolute 1.7e-4 for x < 0 (GELU), absolute 5.4e-4 (GELU');
+    on top of each, the rounding of the bf16 result itself (relative 2^-8)."""
+    import math
+    from mmgclip import kernels as K
+    bits = torch.arange(0, 65536, dtype=torch.int32)
+    x = bits.to(torch.int16).view(torch.bfloat16)
+    x = x[torch.isfinite(x.float())]
+    pad = (-x.numel()) % 8
+    x = torch.cat([x, torch.zeros(pad, dtype=torch.bfloat16)]).to(dev)
+    y = K.gelu(x).float().cpu().double()
+    xd = x.float().cpu().double()
+    ref = 0.5 * xd * (1 + torch.erf(xd / math.sqrt(2)))
+    err = (y - ref).abs()
+    tiny = 1e-37                                            # (subnormal results flush)
+    assert (err[xd > 0] <= (2 ** -8 + 2 ** -11) * ref[xd > 0].abs() + tiny).all()
+    assert (err[xd < 0] <= 2 ** -8 * ref[xd < 0].abs() + 1.7e-4).all()
+    big = xd.abs() > 8                                      # beyond the clamp: identity / (to 1e-6 |x|) zero
+    assert (y[big & (xd > 0)] == xd[big & (xd > 0)]).all() and (y[big & (xd < 0)].abs() <= 1e-6 * xd[big & (xd < 0)].abs()).all()
+    # derivative: mmg_act_grad_bf16 applied to a gradient of ones
+    from mmgclip._hip import call, ptr, stream
+    g = torch.empty_like(x)
+    call("mmg_act_grad_bf16", ptr(torch.ones_like(x)), ptr(x), ptr(g), x.numel(), 0, stream())
+    g = g.float().cpu().double()
+    dref = 0.5 * (1 + torch.erf(xd / math.sqrt(2))) + xd * torch.exp(-0.5 * xd * xd) / math.sqrt(2 * math.pi)
+    assert ((g - dref).abs() <= 2 ** -8 * dref.abs() + 5.5e-4).all()
