@@ -19,6 +19,7 @@
 // The weight-gradient kernel reads both operands with ds_read_b64_tr_b16 (hardware transpose) because the
 // reduction index (the row m) is the slow index of both inputs.
 #include "common.h"
+#include "gemm_tn.h"
 #include <stdlib.h>
 
 #define GEMM_THREADS 256
@@ -473,15 +474,6 @@ MMG_API int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void
 // =============================================================================================
 // TN (weight gradient): C[N1,N2] += A[M,N1]^T B[M,N2], fp32 atomics, reduction split over workgroups
 // =============================================================================================
-struct GemmTN {
-    const bf16_t* A; const bf16_t* B;
-    int M, N1, N2, lda, ldb;
-    float* C; int ldc;
-    float* colsum_a;          // [N1] += column sums of A (bias gradient of the same linear), nullable
-    int tiles1, tiles2, rows_per_chunk;
-    float alpha;
-    int chunks, xcd_order;    // xcd_order: 0 = (tile, chunk) grid, 1 / 2 = XCD-grouped by the B / A block (see the kernel)
-};
 
 #define TN_T 128     // output tile edge
 #define TN_BK 64     // reduction rows per stage
@@ -711,6 +703,13 @@ MMG_API int mmg_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, flo
     // 256-wide tiles on the wider side when it is a multiple of 256 (measured: -6...-19 % on the ConvNeXt shapes, slower on
     // the short BERT reductions where the tile count is what fills the GPU); MMG_TN_WIDE=0 disables
     static const int wide = getenv("MMG_TN_WIDE") ? atoi(getenv("MMG_TN_WIDE")) : 1;
+    // long reductions onto few output columns (ConvNeXt weight gradients): the 8-wave wide-tile kernel (gemm_tn_wide.hip) streams
+    // both operands once per 192x384-class tile; MMG_TN_WIDE8=0 keeps the kernels of this file
+    const int wide8 = getenv("MMG_TN_WIDE8") ? atoi(getenv("MMG_TN_WIDE8")) : 1;
+    if (wide8 && mmg_tn_wide_launch(g, stream)) {
+        MMG_LAUNCH_CHECK("mmg_gemm_tn_bf16");
+        return 0;
+    }
     const bool long_m = M >= 32768;
     if (wide && long_m && N2 >= N1 && N2 % 256 == 0) launch_tn<1, 2, 32>(g, stream);
     else if (wide && long_m && N1 > N2 && N1 % 256 == 0) launch_tn<2, 1, 32>(g, stream);

@@ -166,3 +166,45 @@ def test_nt_fp8_rejects_bad_k(dev):
     a = torch.zeros(128, 96, device=dev, dtype=torch.uint8)
     with pytest.raises(RuntimeError, match="multiple of 128"):
         L.gemm_nt_fp8(a, a)
+
+
+# ---- wide-tile weight-gradient kernel (gemm_tn_wide.hip: M >= 65536, widths that fit 96/192 x 384) ---------------------------
+def test_tn_wide_integer_exact_asymmetric(dev):
+    """Every configuration of the 8-wave kernel on exact small integers (fp32 sums stay exact): 192x384, 384x192, 96x384, 384x96
+    tiles, several tiles per side, asymmetric operands (a transposed or mis-swizzled fragment cannot pass)."""
+    from mmgclip import linalg
+    for M, N1, N2 in ((65536, 192, 384), (65536 + 32, 384, 192), (70000, 96, 384), (65568, 384, 96), (66000, 384, 768), (65536, 768, 384)):
+        g = torch.Generator().manual_seed(M + N1)
+        a = torch.randint(-2, 3, (M, N1), generator=g).float()
+        b = torch.randint(-1, 2, (M, N2), generator=g).float()
+        a[:, 0] = 1.0                                         # column sums that do not cancel
+        out = torch.zeros(N1, N2, device=dev)
+        cs = torch.zeros(N1, device=dev)
+        linalg.gemm_tn_acc(a.to(dev).bfloat16(), b.to(dev).bfloat16(), out, colsum=cs)
+        ref = (a.double().t() @ b.double()).float()
+        assert torch.equal(out.cpu(), ref), (M, N1, N2, float((out.cpu() - ref).abs().max()))
+        assert torch.equal(cs.cpu(), a.sum(0)), (M, N1, N2)
+
+
+@pytest.mark.parametrize("M,N1,N2", [(65536, 96, 384), (131072 + 17, 384, 96), (70001, 192, 768), (65536 * 3, 768, 192), (262144, 384, 1536),
+                                     (100000, 768, 3072), (65536, 128, 512), (65599, 200, 392), (80000, 1024, 256)])
+def test_tn_wide(dev, M, N1, N2, monkeypatch):
+    """Random data incl. ragged M (last stage partly beyond the matrix), widths that need clamped panels (128, 200, 392) and
+    shapes the dispatcher must leave to the 128-wide kernel; both kernels must agree with fp64."""
+    from mmgclip import linalg
+    a, b = _rand((M, N1), dev, 1.0, 7), _rand((M, N2), dev, 1.0, 8)
+    ref = 1.0 + (a.double().t() @ b.double()).float()
+    refc = 2.0 + a.double().sum(0).float()
+    for wide in ("1", "0"):
+        monkeypatch.setenv("MMG_TN_WIDE8", wide)
+        out = torch.ones(N1, N2, device=dev)
+        cs = torch.full((N1,), 2.0, device=dev)
+        linalg.gemm_tn_acc(a, b, out, colsum=cs)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
+        np.testing.assert_allclose(cs.cpu().numpy(), refc.cpu().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
+    # strided operands (a slice of a wider buffer), as the towers pass them
+    big = _rand((M, N2 + 64), dev, 1.0, 9)
+    out = torch.zeros(N1, N2, device=dev)
+    monkeypatch.setenv("MMG_TN_WIDE8", "1")
+    linalg.gemm_tn_acc(a, big[:, 32:32 + N2], out)
+    np.testing.assert_allclose(out.cpu().numpy(), (a.double().t() @ big[:, 32:32 + N2].double()).float().cpu().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
