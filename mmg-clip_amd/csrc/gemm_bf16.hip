@@ -123,8 +123,10 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
                 // the activation itself (needed by the weight-gradient GEMM of the same layer) shares cdf/pdf with
                 // its derivative: emitting it here replaces a separate read-modify-write pass over the [M,N] tensor
                 float a0, d0, a1, d1;
-                if (g.out_f32) { gelu_both(h0, a0, d0); gelu_both(h1, a1, d1); }
-                else { gelu_bf16_both(h0, a0, d0); gelu_bf16_both(h1, a1, d1); }
+                // (the polynomial pair gelu_bf16_both is 7 % SLOWER here - same-run A/B, tools/nt_ab.py: this epilogue is not
+                // VALU-bound and the 9-deep dependent fma chain hides less of its memory latency than the rcp / exp form)
+                gelu_both(h0, a0, d0);
+                gelu_both(h1, a1, d1);
                 v[2 * e] *= d0;
                 v[2 * e + 1] *= d1;
                 act[e] = pack2bf(a0, a1);
@@ -177,7 +179,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int NST, int F8 = 0>
-__global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 128 ? 1 : 2)) void gemm_nt_kernel(const GemmNT g) {
+__global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? (WAVES_M == 4 ? 4 : 3) : (BN > 128 ? 1 : 2)) void gemm_nt_kernel(const GemmNT g) {
     static_assert(!F8 || BK == 64, "fp8 operands: one 128-byte K tile = one 16x16x128 MFMA step");
     constexpr int THREADS = WAVES_M * 128;
     constexpr int MI = 4, NI = BN / 32;                  // 16x16 fragments per wave (wave tile 64 x BN/2)
@@ -211,12 +213,17 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
     const int tr = tid / TPR, tc = (tid % TPR) * 8;
     const int gc = n0 + tc;
     const bool col_ok = (tr < RPP) && (gc < g.N);
+    // (the 128-register two-workgroup tile fetches these after the main loop: 16 registers it cannot keep alive through it)
+    constexpr bool LATE_VECS = NST == 3 && BK == 32 && WAVES_M == 4;
     float bias[8], cs[8];
+    auto fetch_col_vectors = [&]() {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bias[e] = (col_ok && g.bias) ? g.bias[gc + e] : 0.f;
-        cs[e] = (col_ok && g.colscale) ? g.colscale[gc + e] : 1.f;
-    }
+        for (int e = 0; e < 8; ++e) {
+            bias[e] = (col_ok && g.bias) ? g.bias[gc + e] : 0.f;
+            cs[e] = (col_ok && g.colscale) ? g.colscale[gc + e] : 1.f;
+        }
+    };
+    if (!LATE_VECS) fetch_col_vectors();
 
     // ---- per-thread constants of the staging (global byte offsets inside the tile, rows clamped) -----------------
     unsigned a_off[A_IT], b_off[B_IT];
@@ -321,9 +328,11 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
         }
     }
 
+    if (LATE_VECS) fetch_col_vectors();
     // issue EVERY global read of the epilogue (residual / saved pre-activation rows of all passes) before the
     // accumulators go through LDS, so their latency overlaps the staging instead of being paid pass by pass.
-    constexpr bool PREFETCH = PASSES <= 8;                // (wider tiles: 16 passes of prefetch would spill)
+    // (wider tiles: 16 passes of prefetch would spill; the 128-register two-workgroup tile has no room for it either)
+    constexpr bool PREFETCH = PASSES <= 8 && !(NST == 3 && BK == 32 && WAVES_M == 4);
     uint4 res_v[PREFETCH ? PASSES : 1], aux_v[PREFETCH ? PASSES : 1];
     const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DRELU);
     const float alpha = g.alpha_dev ? g.alpha * *g.alpha_dev : g.alpha;
@@ -432,6 +441,10 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     auto fill = [](long wgs) { return (double)wgs / (double)(cdiv(wgs, 256) * 256L); };
     const double f256 = fill((long)cdiv(M, 256) * cdiv(N, 256)), f128 = fill((long)cdiv(M, 256) * cdiv(N, 128));
     const bool fills = !fill_rule || f256 >= 0.8 * f128;
+    // experiment knob: 256x128 tiles of 8 waves (wave tile 64x64), 32-deep stages in a ring of three, TWO workgroups per CU (4 waves
+    // per SIMD) so that one workgroup's activation epilogue overlaps the other's main loop
+    const int wg2 = getenv("MMG_GEMM_2WG") ? atoi(getenv("MMG_GEMM_2WG")) : 0;
+    if (wg2 && N % 128 == 0 && M >= 4096 && K % 32 == 0) { launch_nt<256, 128, 32, 4, 3>(g, stream); MMG_LAUNCH_CHECK("mmg_gemm_nt_bf16"); return 0; }
     if (use_256 && k64 && N % 256 == 0 && M >= 4096 && K >= use_256 && fills) launch_nt<256, 256, 64, 4, 2>(g, stream);
     else if (use_3wg && !n96 && K % 32 == 0 && K < k3_max) launch_nt<128, 128, 32, 2, 3>(g, stream);
     else if (use_big && k64 && !n96 && M >= 4096 && K >= kbig_min) launch_nt<256, 128, 64, 4, 3>(g, stream);
