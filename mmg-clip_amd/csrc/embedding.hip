@@ -105,8 +105,11 @@ MMG_API int mmg_bert_embed_bwd(const void* g, const long long* ids, const long l
 }
 
 // out[b,:] = hidden[b*S + idx_b, :] with idx_b = sum(mask[b,:]) - 1   (EOS pooling, mmgclip_model.py:110-111); fp32 out
-__global__ __launch_bounds__(256) void eos_pool_kernel(const bf16_t* __restrict__ hidden, const long long* __restrict__ mask,
+template <bool F32>
+__global__ __launch_bounds__(256) void eos_pool_kernel(const void* __restrict__ hidden_, const long long* __restrict__ mask,
                                                        float* __restrict__ out, int* __restrict__ idx_out, int S, int H) {
+    const bf16_t* hidden = reinterpret_cast<const bf16_t*>(hidden_);
+    const float* hidden32 = reinterpret_cast<const float*>(hidden_);
     __shared__ int s_idx;
     const int b = blockIdx.x;
     if (threadIdx.x < 64) {
@@ -123,13 +126,22 @@ __global__ __launch_bounds__(256) void eos_pool_kernel(const bf16_t* __restrict_
     }
     __syncthreads();
     const int i = s_idx;
-    for (int c = threadIdx.x; c < H; c += 256) out[(size_t)b * H + c] = bf2f(hidden[((size_t)b * S + i) * H + c]);
+    for (int c = threadIdx.x; c < H; c += 256)
+        out[(size_t)b * H + c] = F32 ? hidden32[((size_t)b * S + i) * H + c] : bf2f(hidden[((size_t)b * S + i) * H + c]);
 }
 MMG_API int mmg_eos_pool_fwd(const void* hidden, const long long* mask, float* out, int* idx_out, int B, int S, int H,
                              hipStream_t stream) {
     MMG_CHECK_ARG(hidden && mask && out && B > 0 && S > 0 && H > 0, "mmg_eos_pool_fwd: bad argument");
-    hipLaunchKernelGGL(eos_pool_kernel, dim3(B), dim3(256), 0, stream, (const bf16_t*)hidden, mask, out, idx_out, S, H);
+    hipLaunchKernelGGL(eos_pool_kernel<false>, dim3(B), dim3(256), 0, stream, hidden, mask, out, idx_out, S, H);
     MMG_LAUNCH_CHECK("mmg_eos_pool_fwd");
+    return 0;
+}
+// the same gather from an fp32 hidden state (the text tower hands over its fp32 residual stream: no rounding before the projection)
+MMG_API int mmg_eos_pool_fwd_f32(const float* hidden, const long long* mask, float* out, int* idx_out, int B, int S, int H,
+                                 hipStream_t stream) {
+    MMG_CHECK_ARG(hidden && mask && out && B > 0 && S > 0 && H > 0, "mmg_eos_pool_fwd_f32: bad argument");
+    hipLaunchKernelGGL(eos_pool_kernel<true>, dim3(B), dim3(256), 0, stream, (const void*)hidden, mask, out, idx_out, S, H);
+    MMG_LAUNCH_CHECK("mmg_eos_pool_fwd_f32");
     return 0;
 }
 // dhidden = 0 except row idx_b of each sequence = dout[b,:]  (bf16)

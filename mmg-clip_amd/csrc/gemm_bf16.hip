@@ -33,6 +33,7 @@ struct GemmNT {
     const float* bias;        // [N]  added to the accumulator
     const float* colscale;    // [N]  multiplies after activation (ConvNeXt layer scale)
     const bf16_t* residual; int ldr;   // [M,N] added last
+    int res_f32;                       // residual holds fp32 (the text tower's fp32 residual stream); ldr in elements
     const bf16_t* aux_in; int ldai;    // [M,N] pre-activation for EPI_DGELU / EPI_DRELU
     bf16_t* aux_out; int ldao;         // [M,N] receives the pre-activation for EPI_GELU / EPI_RELU (may be null)
     int epi;
@@ -140,7 +141,11 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= cs[e];
-    if (g.residual) {
+    if (g.residual && g.res_f32) {          // (read here, not prefetched with the bf16 rows: only the small text-tower GEMMs use it)
+        const float* rp = reinterpret_cast<const float*>(g.residual) + (size_t)gr * g.ldr + gc;
+        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    } else if (g.residual) {
         const unsigned rw[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? (WAVES_M ==
         const bool ok = col_ok && (rl < 64) && (gr < g.M);
         res_v[p] = make_uint4(0, 0, 0, 0);
         aux_v[p] = make_uint4(0, 0, 0, 0);
-        if (ok && g.residual) res_v[p] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
+        if (ok && g.residual && !g.res_f32) res_v[p] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
         if (ok && want_aux) aux_v[p] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
     }
     // accumulators -> LDS -> coalesced 16-byte row segments, one 64-row slab (= one wave row) at a time
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? (WAVES_M ==
                 const bool ok = col_ok && (rl < 64) && (gr < g.M);
                 rs_v[hp] = make_uint4(0, 0, 0, 0);
                 as_v[hp] = make_uint4(0, 0, 0, 0);
-                if (ok && g.residual) rs_v[hp] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
+                if (ok && g.residual && !g.res_f32) rs_v[hp] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
                 if (ok && want_aux) as_v[hp] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
             }
         }
@@ -416,7 +421,8 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     MMG_CHECK_ARG(!aux_out || (ldao >= N && ldao % 8 == 0), "mmg_gemm_nt_bf16: bad ldao=%d", ldao);
     GemmNT g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
-    g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.bias = bias; g.colscale = colscale;
+    // out_f32: bit 0 = C is fp32, bit 1 = residual is fp32 (ldr in fp32 elements)
+    g.C = C; g.ldc = ldc; g.res_f32 = (out_f32 >> 1) & 1; out_f32 &= 1; g.out_f32 = out_f32; g.bias = bias; g.colscale = colscale;
     g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = (const bf16_t*)aux_in; g.ldai = ldai;
     g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.out_fp8 = 0; g.alpha_dev = nullptr;
     static const int force_bk = getenv("MMG_GEMM_BK") ? atoi(getenv("MMG_GEMM_BK")) : 0;   // tuning knobs
@@ -473,7 +479,7 @@ MMG_API int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void
     GemmNT g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
     g.C = C; g.ldc = ldc; g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 2; g.bias = bias; g.colscale = colscale;
-    g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = nullptr; g.ldai = 0;
+    g.residual = (const bf16_t*)residual; g.ldr = ldr; g.res_f32 = 0; g.aux_in = nullptr; g.ldai = 0;
     g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.alpha_dev = alpha_dev;
     g.nt_store = (size_t)M * N * (out_kind == 1 ? 4 : out_kind == 2 ? 1 : 2) >= ((size_t)256 << 20);
     static const int tile = getenv("MMG_FP8_TILE") ? atoi(getenv("MMG_FP8_TILE")) : 0;   // tuning: 1 = 256x128, 2 = 128x128

@@ -31,7 +31,22 @@ struct LNArgs {
     const bf16_t* add; int ldadd;    // optional residual-path gradient added to dx (pre-LN transformer blocks)
     int nt;                          // stream the output past L2 (tensor larger than the Infinity Cache)
     int y_fp8;                       // y receives OCP e4m3 bytes (ldy in bytes): operand of the fp8 GEMM path
+    int x_f32;                       // x holds fp32 (the text tower keeps its pre-LayerNorm sums in fp32); ldx in elements
+    float* yf; int ldyf;             // optional fp32 copy of y (the text tower's residual stream), forward only
 };
+
+// 8 consecutive elements of row m of x (bf16 or fp32 storage) as floats
+__device__ __forceinline__ void ln_load_x8(const LNArgs& a, int m, int c, float* v) {
+    if (a.x_f32) {
+        const float* p = reinterpret_cast<const float*>(a.x) + (size_t)m * a.ldx + c * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    } else {
+        const uint4 r = *reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx + c * 8);
+        v[0] = bf2f_lo(r.x); v[1] = bf2f_hi(r.x); v[2] = bf2f_lo(r.y); v[3] = bf2f_hi(r.y);
+        v[4] = bf2f_lo(r.z); v[5] = bf2f_hi(r.z); v[6] = bf2f_lo(r.w); v[7] = bf2f_hi(r.w);
+    }
+}
 
 // returns (size_t)-1 for pixels of an odd last row / column: a 2x2 stride-2 convolution never reads them
 __device__ __forceinline__ size_t ln_out_offset(const LNArgs& a, int m, int ld) {
@@ -73,7 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const LNArgs a) {
         for (int k = 0; k < CH; ++k) {
             const int c = gl + k * G;
             if (c < nchunks) {
-                unpack8(*reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx + c * 8), v[k]);
+                ln_load_x8(a, m, c, v[k]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += v[k][e];
             }
@@ -103,6 +118,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const LNArgs a) {
                     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(a.y) + obase + c * 8) =
                         make_uint2(pack4_e4m3(o[0], o[1], o[2], o[3]), pack4_e4m3(o[4], o[5], o[6], o[7]));
                 else if (obase != (size_t)-1) store16_stream(a.y + obase + c * 8, pack8(o), a.nt);
+                if (a.yf) {
+                    float* q = a.yf + (size_t)m * a.ldyf + c * 8;
+                    *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(q + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                }
             }
         }
         if (gl == 0) {
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LNArgs a) {
             const int c = gl + k * G;
             if (c < nchunks) {
                 float xv[8], dyv[8];
-                unpack8(*reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx + c * 8), xv);
+                ln_load_x8(a, m, c, xv);
                 unpack8(*reinterpret_cast<const uint4*>(a.dy + gbase + c * 8), dyv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -236,6 +256,37 @@ MMG_API int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const 
     a.nt = (size_t)M * C * 2 >= ((size_t)256 << 20);
     if (launch_ln<false>(a, stream)) return 1;
     MMG_LAUNCH_CHECK("mmg_layernorm_fwd");
+    return 0;
+}
+
+// LayerNorm of an fp32 input row (the text tower's pre-LayerNorm sums x + f(x) stay in fp32: bf16 rounding of the residual
+// stream is what owned the end-to-end loss error at BASELINE config C1); y bf16 (GEMM operand) + optional fp32 copy yf.
+MMG_API int mmg_layernorm_fwd_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
+                                  float* yf, int ldyf, float* mean, float* rstd, int M, int C, hipStream_t stream) {
+    if (ln_check("mmg_layernorm_fwd_f32", M, C, 0, 0, 0)) return 1;
+    MMG_CHECK_ARG(x && gamma && beta && y && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C && (!yf || (ldyf >= C && ldyf % 4 == 0)),
+                  "mmg_layernorm_fwd_f32: bad pointer or leading dimension");
+    LNArgs a = {};
+    a.x = reinterpret_cast<const bf16_t*>(x); a.x_f32 = 1; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.y = (bf16_t*)y; a.ldy = ldy; a.yf = yf; a.ldyf = ldyf; a.mean = mean; a.rstd = rstd; a.M = M; a.C = C;
+    if (launch_ln<false>(a, stream)) return 1;
+    MMG_LAUNCH_CHECK("mmg_layernorm_fwd_f32");
+    return 0;
+}
+MMG_API int mmg_layernorm_bwd_f32(const void* dy, int lddy, const float* x, int ldx, const float* mean, const float* rstd,
+                                  const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta, int M, int C,
+                                  const void* add, int ldadd, hipStream_t stream) {
+    if (ln_check("mmg_layernorm_bwd_f32", M, C, 0, 0, 0)) return 1;
+    MMG_CHECK_ARG(dy && x && mean && rstd && gamma && dx && ((dgamma == nullptr) == (dbeta == nullptr)) && ldx % 8 == 0 &&
+                      lddy % 8 == 0 && lddx % 8 == 0 && ldx >= C && lddx >= C && (!add || (ldadd >= C && ldadd % 8 == 0)),
+                  "mmg_layernorm_bwd_f32: bad pointer or leading dimension");
+    LNArgs a = {};
+    a.x = reinterpret_cast<const bf16_t*>(x); a.x_f32 = 1; a.ldx = ldx; a.gamma = gamma;
+    a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.M = M; a.C = C;
+    a.dy = (const bf16_t*)dy; a.lddy = lddy; a.dx = (bf16_t*)dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.add = (const bf16_t*)add; a.ldadd = ldadd;
+    if (launch_ln<true>(a, stream)) return 1;
+    MMG_LAUNCH_CHECK("mmg_layernorm_bwd_f32");
     return 0;
 }
 

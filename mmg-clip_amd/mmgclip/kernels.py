@@ -30,6 +30,28 @@ def layernorm_fwd(x, gamma, beta, eps, patch_hw=None, want_stats=True):
     return y, mean, rstd
 
 
+def layernorm_fwd_f32(x, gamma, beta, eps, want_stats=True, want_f32=False):
+    """x fp32 [M,C] -> y bf16 [M,C], yf (fp32 copy of y or None), mean, rstd  (text tower: pre-LayerNorm sums stay fp32)."""
+    M, C = x.shape
+    assert x.dtype == torch.float32
+    y = torch.empty(M, C, device=x.device, dtype=BF16)
+    yf = torch.empty(M, C, device=x.device, dtype=torch.float32) if want_f32 else None
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
+    call("mmg_layernorm_fwd_f32", ptr(x), x.stride(0), ptr(gamma), ptr(beta), float(eps), ptr(y), y.stride(0), ptr(yf),
+         C if want_f32 else 0, ptr(mean), ptr(rstd), M, C, stream())
+    return y, yf, mean, rstd
+
+
+def layernorm_bwd_f32(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, add=None):
+    M, C = x.shape
+    assert x.dtype == torch.float32
+    dx = torch.empty(M, C, device=x.device, dtype=BF16)
+    call("mmg_layernorm_bwd_f32", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+         dx.stride(0), ptr(dgamma), ptr(dbeta), M, C, ptr(add), add.stride(0) if add is not None else 0, stream())
+    return dx
+
+
 def layernorm_fwd_fp8(x, gamma, beta, eps, want_stats=True):
     """x bf16 [M,C] -> y e4m3 bytes (uint8 [M,C], unscaled, saturating), mean, rstd: operand of linalg.gemm_nt_fp8."""
     M, C = x.shape
@@ -235,7 +257,8 @@ def eos_pool_fwd(hidden, mask, B, S):
     H = hidden.shape[1]
     out = torch.empty(B, H, device=hidden.device, dtype=torch.float32)
     idx = torch.empty(B, device=hidden.device, dtype=torch.int32)
-    call("mmg_eos_pool_fwd", ptr(hidden), ptr(mask), ptr(out), ptr(idx), B, S, H, stream())
+    call("mmg_eos_pool_fwd_f32" if hidden.dtype == torch.float32 else "mmg_eos_pool_fwd", ptr(hidden), ptr(mask), ptr(out), ptr(idx),
+         B, S, H, stream())
     return out, idx
 
 

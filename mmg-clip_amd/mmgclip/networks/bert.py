@@ -192,21 +192,27 @@ class BertTower(nn.Module):
         rows, cu = pack if pack is not None else (None, None)
         if rows is not None:
             emb = emb.index_select(0, rows)                  # [T, H]: the valid tokens, sequence after sequence
-        x, mean, rstd = K.layernorm_fwd(emb, e.LayerNorm.weight.data, e.LayerNorm.bias.data, eps, want_stats=save)
+        # The residual stream and the pre-LayerNorm sums x + sublayer(x) are kept in fp32 (`xf`, `a`, `f`); every GEMM still reads a
+        # bf16 copy of the stream (`x`).  Measured at BASELINE config C1 (tests/test_c1_gpu.py): with a bf16 stream the text tower
+        # owned the end-to-end loss error (1e-3 relative, the north star's bar); BERT is 5 % of the step, so the fp32 rows are free.
+        x, xf, mean, rstd = K.layernorm_fwd_f32(emb.float(), e.LayerNorm.weight.data, e.LayerNorm.bias.data, eps, want_stats=save,
+                                                want_f32=True)
         saved = {"emb": (emb, mean, rstd), "layers": [], "shape": (B, S), "tok": (ids, tt, mask), "pack": pack} if save else None
         for i, lyr in enumerate(self.model.encoder.layer):
             qkv = L.gemm_nt(x, wc[f"{i}.wqkv"], bias=wc[f"{i}.bqkv"][:3 * cfg.hidden_size])
             ctx, lse = K.attention_fwd(qkv, mask, B, S, heads, want_lse=save, cu=cu)
-            a = L.gemm_nt(ctx, wc[f"{i}.wo"], bias=lyr.attention.output.dense.bias.data, residual=x)
-            x1, m1, r1 = K.layernorm_fwd(a, lyr.attention.output.LayerNorm.weight.data, lyr.attention.output.LayerNorm.bias.data,
-                                         eps, want_stats=save)
+            a = L.gemm_nt(ctx, wc[f"{i}.wo"], bias=lyr.attention.output.dense.bias.data, residual=xf, out_dtype=torch.float32)
+            x1, x1f, m1, r1 = K.layernorm_fwd_f32(a, lyr.attention.output.LayerNorm.weight.data, lyr.attention.output.LayerNorm.bias.data,
+                                                  eps, want_stats=save, want_f32=True)
             hpre = torch.empty(x.shape[0], cfg.intermediate_size, device=x.device, dtype=torch.bfloat16) if save else None
             g = L.gemm_nt(x1, wc[f"{i}.wi"], bias=lyr.intermediate.dense.bias.data, epi=L.EPI_GELU, aux_out=hpre)
-            f = L.gemm_nt(g, wc[f"{i}.wf"], bias=lyr.output.dense.bias.data, residual=x1)
-            x2, m2, r2 = K.layernorm_fwd(f, lyr.output.LayerNorm.weight.data, lyr.output.LayerNorm.bias.data, eps, want_stats=save)
+            f = L.gemm_nt(g, wc[f"{i}.wf"], bias=lyr.output.dense.bias.data, residual=x1f, out_dtype=torch.float32)
+            x2, x2f, m2, r2 = K.layernorm_fwd_f32(f, lyr.output.LayerNorm.weight.data, lyr.output.LayerNorm.bias.data, eps,
+                                                  want_stats=save, want_f32=True)
             if save:
                 saved["layers"].append((x, qkv, ctx, lse, a, m1, r1, x1, hpre, f, m2, r2))
-            x = x2
+            x, xf = x2, x2f
+        x = xf                                               # the tower's output is the fp32 stream (EOS pooling gathers fp32 rows)
         if rows is not None:                                 # back to the padded [B*S, H] layout (padding rows: zeros)
             full = torch.zeros(B * S, x.shape[1], device=x.device, dtype=x.dtype)
             full.index_copy_(0, rows, x)
@@ -225,8 +231,8 @@ class BertTower(nn.Module):
             lyr = self.model.encoder.layer[i]
             p = f"encoder.layer.{i}."
             x, qkv, ctx, lse, a, m1, r1, x1, hpre, f, m2, r2 = saved["layers"][i]
-            df = K.layernorm_bwd(dx, f, m2, r2, lyr.output.LayerNorm.weight.data, A.g(p + "output.LayerNorm.weight"),
-                                 A.g(p + "output.LayerNorm.bias"))
+            df = K.layernorm_bwd_f32(dx, f, m2, r2, lyr.output.LayerNorm.weight.data, A.g(p + "output.LayerNorm.weight"),
+                                     A.g(p + "output.LayerNorm.bias"))
             g = torch.empty_like(hpre)                     # GELU(hpre), rebuilt by the same epilogue that applies GELU'
             dh = L.gemm_nt(df, wc[f"{i}.wft"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
             L.gemm_tn_acc(df, g, A.g(p + "output.dense.weight"), colsum=A.g(p + "output.dense.bias"))
@@ -234,8 +240,8 @@ class BertTower(nn.Module):
             L.gemm_tn_acc(dh, x1, A.g(p + "intermediate.dense.weight"), colsum=A.g(p + "intermediate.dense.bias"))
             dx1 = L.gemm_nt(dh, wc[f"{i}.wit"], residual=df)          # + residual path of the FFN block
             del dh, df
-            da = K.layernorm_bwd(dx1, a, m1, r1, lyr.attention.output.LayerNorm.weight.data,
-                                 A.g(p + "attention.output.LayerNorm.weight"), A.g(p + "attention.output.LayerNorm.bias"))
+            da = K.layernorm_bwd_f32(dx1, a, m1, r1, lyr.attention.output.LayerNorm.weight.data,
+                                     A.g(p + "attention.output.LayerNorm.weight"), A.g(p + "attention.output.LayerNorm.bias"))
             del dx1
             L.gemm_tn_acc(da, ctx, A.g(p + "attention.output.dense.weight"), colsum=A.g(p + "attention.output.dense.bias"))
             dctx = L.gemm_nt(da, wc[f"{i}.wot"])
@@ -260,7 +266,7 @@ class BertTower(nn.Module):
 
     # ---- public -----------------------------------------------------------------------------------------------------
     def forward(self, input_ids, attention_mask=None, token_type_ids=None, packed=None, **_):
-        """-> last_hidden_state as bf16 [B*S, H] (use .view(B, S, H).float() for the HF-shaped tensor).
+        """-> last_hidden_state as fp32 [B*S, H] (the tower's fp32 residual stream; .view(B, S, H) for the HF-shaped tensor).
         packed=True (default: self.packed) computes the rows of valid tokens only and leaves zeros in the padding rows;
         packed=False reproduces HF's values there too."""
         _hip.require_gpu(input_ids)

@@ -158,7 +158,7 @@ class BertEncoder(BertTower):
                 param.requires_grad = False
 
     def hidden_states(self, x, packed=None):
-        """bf16 [B*S, H] last hidden state (device layout, autograd-connected).  By default only the rows of valid tokens are
+        """fp32 [B*S, H] last hidden state (device layout, autograd-connected).  By default only the rows of valid tokens are
         computed (right-padded prompts; padding rows come back as zeros) - all that EOS pooling reads."""
         return BertTower.forward(self, x["input_ids"], x.get("attention_mask"), x.get("token_type_ids"), packed=packed)
 

@@ -150,9 +150,10 @@ def test_nt_fp8_epilogues(dev, M, N, K):
     assert float((aux.cpu().double() - pre_ref).abs().max()) < 1e-2 * float(pre_ref.abs().max())       # bf16 storage
     h_ref = q_e4m3(torch.nn.functional.gelu(pre_ref).float())
     h = h8.cpu().view(torch.float8_e4m3fn).float()
-    # an e4m3 step is 6-12 % of the value: a result on a rounding boundary may land on either neighbour, never further
+    # an e4m3 step is 6-12 % of the value: a result on a rounding boundary may land on either neighbour, never further.  The
+    # polynomial GELU (relative error <= 4.3e-4, common.h) moves results within 2 * 4.3e-4 / 0.06 ~ 1.4 % of a boundary across it.
     mism = (h != h_ref)
-    assert float(mism.float().mean()) < 5e-3, float(mism.float().mean())
+    assert float(mism.float().mean()) < 1.5e-2, float(mism.float().mean())
     assert bool(((h - h_ref).abs() <= torch.maximum(0.126 * torch.maximum(h.abs(), h_ref.abs()), torch.tensor(2.0 ** -9))).all())
     out = L.gemm_nt_fp8(a8.to(dev), b8.to(dev), bias=bias.to(dev), colscale=cs.to(dev), residual=res.to(dev), alpha=0.25,
                         alpha_dev=alpha_dev)

@@ -139,8 +139,7 @@ def test_resnet50_image_encoder_config(dev, monkeypatch):
     assert trainable == {"image_encoder.layer4", "image_projection_layer.layer.weight", "text_projection_layer.layer.weight"}
     assert model.image_projection_layer.layer.weight.shape == (512, 2048)
     batch = synthetic_batch(16, S=77, vocab_size=3000, seed=4)
-    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-4,
-                     arenas=[model.image_encoder.arena] if model.image_encoder.arena is not None else [])
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-4)   # built before any arena exists
     crit = create_loss("CLIPLoss")()
     losses = []
     w_frozen = model.image_encoder.model.layer1[0].conv1.weight.detach().clone()
@@ -148,9 +147,7 @@ def test_resnet50_image_encoder_config(dev, monkeypatch):
         opt.zero_grad(set_to_none=True)
         loss, _ = crit(**model(batch))
         loss.backward()
-        if not opt.arenas and model.image_encoder.arena is not None:
-            opt.arenas.append(model.image_encoder.arena)
-        opt.step()
+        opt.step()            # partially trainable arena (layer4 only): per-tensor updates, and the arena is told (touch)
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert torch.equal(w_frozen, model.image_encoder.model.layer1[0].conv1.weight.detach())

@@ -20,6 +20,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):
     fam = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+    fam = {"gemm_tn_wide_kernel": "gemm_tn_kernel"}.get(fam, fam)
     agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
     n[fam].add(r["Dispatch_Id"])
 res = {}

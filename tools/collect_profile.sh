@@ -26,7 +26,9 @@ for r in rows[:24]:
 md += ["", f"Sum of kernel time {tot/1e6:.0f} ms over {steps} steps = {tot/1e6/steps:.0f} ms/step vs {b['ms_per_step']:.0f} ms/step wall under the profiler.", ""]
 for rl in [b["roofline"]] + b.get("roofline_other_kernels", []):
     fam = rl["kernel"]
-    sel = [r for r in rows if r["Name"].replace("void ", "").split("<")[0].split("(")[0].strip() == fam]
+    # (the weight-gradient family is two kernels: gemm_tn_kernel and the wide-tile gemm_tn_wide_kernel; bench.py times both as one)
+    base = lambda n: {"gemm_tn_wide_kernel": "gemm_tn_kernel"}.get(n, n)
+    sel = [r for r in rows if base(r["Name"].replace("void ", "").split("<")[0].split("(")[0].strip()) == fam]
     if not sel:
         continue
     n = sum(int(r["Calls"]) for r in sel); t = sum(float(r["TotalDurationNs"]) for r in sel)

@@ -32,6 +32,7 @@ for k, (n, kb) in res["FETCH_SIZE"].items():
 fam = collections.defaultdict(lambda: [0, 0.0])        # kernel family = symbol name without template arguments
 for k, v in kernels.items():
     f = k.replace("void ", "").split("<")[0].strip()
+    f = {"gemm_tn_wide_kernel": "gemm_tn_kernel"}.get(f, f)        # one family for bench.py: both weight-gradient kernels
     fam[f][0] += v["launches"]
     fam[f][1] += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
 families = {f: {"launches": n, "hbm_bytes_per_launch": tot / n} for f, (n, tot) in fam.items() if n}
