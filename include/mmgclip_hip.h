@@ -87,8 +87,7 @@ int mmg_clip_loss_reduce(const float* lse_a, const float* pos_a, const float* ls
  *     0 none | 1 GELU(erf) (aux_out, when given, receives the pre-activation) | 2 multiply by GELU'(aux_in)
  *     (aux_out, when given, receives GELU(aux_in): the activation rebuilt for the weight-gradient GEMM)
  *     3 ReLU (aux_out as 1)  | 4 ReLU' (gate by aux_in > 0; aux_out as 2);
- * then * colscale[N] (ConvNeXt layer scale), + residual[M,N]; out_f32 bit 0: C is fp32 (else bf16), bit 1: residual is fp32
- * (else bf16; ldr in elements of its type) - the text tower keeps its residual stream and pre-LayerNorm sums in fp32.
+ * then * colscale[N] (ConvNeXt layer scale), + residual[M,N] (bf16); C is bf16 (out_f32 = 0) or fp32.
  * K % 32 == 0, N % 8 == 0, leading dimensions multiples of 8.
  * Replaces nn.Linear forward / data-gradient in HF BertLayer (reference call site mmgclip/networks/encoder.py:156),
  * torchvision CNBlock + patchify convs (mmgclip/networks/encoder.py:53, mmgclip/networks/image_features.py:100)
@@ -116,9 +115,10 @@ int mmg_colsum_bf16(const void* A, int lda, int M, int N, float* out, mmg_stream
 int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
                       float* mean, float* rstd, int M, int C, int patch, int H, int W, mmg_stream_t stream);
 /* The same LayerNorm on an fp32 input row (HF BertLayer's LayerNorm(x + sublayer(x)), mmgclip/networks/encoder.py:156, with the
- * sum kept in fp32): y bf16 (operand of the next GEMM) and, when yf != NULL, an fp32 copy (the residual of the next sum). */
-int mmg_layernorm_fwd_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
-                          float* yf, int ldyf, float* mean, float* rstd, int M, int C, mmg_stream_t stream);
+ * sum kept in fp32).  res (fp32 [M,C], nullable): x <- x + res IN PLACE first (x then holds the pre-LayerNorm sum the backward
+ * needs).  y bf16 (operand of the next GEMM) and, when yf != NULL, an fp32 copy of it (the residual of the next sum). */
+int mmg_layernorm_fwd_f32(float* x, int ldx, const float* res, int ldres, const float* gamma, const float* beta, float eps,
+                          void* y, int ldy, float* yf, int ldyf, float* mean, float* rstd, int M, int C, mmg_stream_t stream);
 int mmg_layernorm_bwd_f32(const void* dy, int lddy, const float* x, int ldx, const float* mean, const float* rstd,
                           const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta, int M, int C,
                           const void* add, int ldadd, mmg_stream_t stream);

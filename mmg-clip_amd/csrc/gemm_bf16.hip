@@ -33,7 +33,6 @@ struct GemmNT {
     const float* bias;        // [N]  added to the accumulator
     const float* colscale;    // [N]  multiplies after activation (ConvNeXt layer scale)
     const bf16_t* residual; int ldr;   // [M,N] added last
-    int res_f32;                       // residual holds fp32 (the text tower's fp32 residual stream); ldr in elements
     const bf16_t* aux_in; int ldai;    // [M,N] pre-activation for EPI_DGELU / EPI_DRELU
     bf16_t* aux_out; int ldao;         // [M,N] receives the pre-activation for EPI_GELU / EPI_RELU (may be null)
     int epi;
@@ -96,6 +95,9 @@ __device__ __forceinline__ void store16(void* dst, const uint4 v, int nt) {
 }
 
 // One output row segment of 8 columns: staged fp32 accumulators -> bias / activation / layer scale / residual -> store.
+// This epilogue is touchy (round 2, same-run A/B of five builds, tools/nt_ab.py): on the 1M x 1536 x 384 GELU' shape the polynomial
+// GELU of common.h was 7 % slower than the rcp / exp form (the epilogue is not VALU-bound; its 9-deep fma chain hides less memory
+// latency), a runtime fp32-residual branch cost 4-6 %, a further co-compiled tile instantiation 3 %: it stays as round 1 left it.
 __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* crow, int gr, int gc, const float* bias,
                                                 const float* cs, const uint4 res, const uint4 aux, bool want_aux, float alpha) {
     float v[8];
@@ -112,8 +114,7 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
             store16(g.aux_out + (size_t)gr * g.ldao + gc, o, g.nt_store);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e)      // bf16 / e4m3 results take the polynomial form (common.h), fp32 results the 1.5e-7 one
-            v[e] = (g.epi == EPI_GELU) ? (g.out_f32 ? gelu_f(v[e]) : gelu_bf16(v[e])) : fmaxf(v[e], 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
     } else if (want_aux) {
         const unsigned hw[4] = {aux.x, aux.y, aux.z, aux.w};
         unsigned act[4];
@@ -124,8 +125,6 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
                 // the activation itself (needed by the weight-gradient GEMM of the same layer) shares cdf/pdf with
                 // its derivative: emitting it here replaces a separate read-modify-write pass over the [M,N] tensor
                 float a0, d0, a1, d1;
-                // (the polynomial pair gelu_bf16_both is 7 % SLOWER here - same-run A/B, tools/nt_ab.py: this epilogue is not
-                // VALU-bound and the 9-deep dependent fma chain hides less of its memory latency than the rcp / exp form)
                 gelu_both(h0, a0, d0);
                 gelu_both(h1, a1, d1);
                 v[2 * e] *= d0;
@@ -141,11 +140,7 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= cs[e];
-    if (g.residual && g.res_f32) {          // (read here, not prefetched with the bf16 rows: only the small text-tower GEMMs use it)
-        const float* rp = reinterpret_cast<const float*>(g.residual) + (size_t)gr * g.ldr + gc;
-        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-    } else if (g.residual) {
+    if (g.residual) {
         const unsigned rw[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
@@ -184,7 +179,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int NST, int F8 = 0>
-__global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? (WAVES_M == 4 ? 4 : 3) : (BN > 128 ? 1 : 2)) void gemm_nt_kernel(const GemmNT g) {
+__global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 128 ? 1 : 2)) void gemm_nt_kernel(const GemmNT g) {
     static_assert(!F8 || BK == 64, "fp8 operands: one 128-byte K tile = one 16x16x128 MFMA step");
     constexpr int THREADS = WAVES_M * 128;
     constexpr int MI = 4, NI = BN / 32;                  // 16x16 fragments per wave (wave tile 64 x BN/2)
@@ -218,17 +213,12 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? (WAVES_M ==
     const int tr = tid / TPR, tc = (tid % TPR) * 8;
     const int gc = n0 + tc;
     const bool col_ok = (tr < RPP) && (gc < g.N);
-    // (the 128-register two-workgroup tile fetches these after the main loop: 16 registers it cannot keep alive through it)
-    constexpr bool LATE_VECS = NST == 3 && BK == 32 && WAVES_M == 4;
     float bias[8], cs[8];
-    auto fetch_col_vectors = [&]() {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            bias[e] = (col_ok && g.bias) ? g.bias[gc + e] : 0.f;
-            cs[e] = (col_ok && g.colscale) ? g.colscale[gc + e] : 1.f;
-        }
-    };
-    if (!LATE_VECS) fetch_col_vectors();
+    for (int e = 0; e < 8; ++e) {
+        bias[e] = (col_ok && g.bias) ? g.bias[gc + e] : 0.f;
+        cs[e] = (col_ok && g.colscale) ? g.colscale[gc + e] : 1.f;
+    }
 
     // ---- per-thread constants of the staging (global byte offsets inside the tile, rows clamped) -----------------
     unsigned a_off[A_IT], b_off[B_IT];
@@ -333,11 +323,9 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? (WAVES_M ==
         }
     }
 
-    if (LATE_VECS) fetch_col_vectors();
     // issue EVERY global read of the epilogue (residual / saved pre-activation rows of all passes) before the
     // accumulators go through LDS, so their latency overlaps the staging instead of being paid pass by pass.
-    // (wider tiles: 16 passes of prefetch would spill; the 128-register two-workgroup tile has no room for it either)
-    constexpr bool PREFETCH = PASSES <= 8 && !(NST == 3 && BK == 32 && WAVES_M == 4);
+    constexpr bool PREFETCH = PASSES <= 8;                // (wider tiles: 16 passes of prefetch would spill)
     uint4 res_v[PREFETCH ? PASSES : 1], aux_v[PREFETCH ? PASSES : 1];
     const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DRELU);
     const float alpha = g.alpha_dev ? g.alpha * *g.alpha_dev : g.alpha;
@@ -348,7 +336,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? (WAVES_M ==
         const bool ok = col_ok && (rl < 64) && (gr < g.M);
         res_v[p] = make_uint4(0, 0, 0, 0);
         aux_v[p] = make_uint4(0, 0, 0, 0);
-        if (ok && g.residual && !g.res_f32) res_v[p] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
+        if (ok && g.residual) res_v[p] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
         if (ok && want_aux) aux_v[p] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
     }
     // accumulators -> LDS -> coalesced 16-byte row segments, one 64-row slab (= one wave row) at a time
@@ -365,7 +353,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? (WAVES_M ==
                 const bool ok = col_ok && (rl < 64) && (gr < g.M);
                 rs_v[hp] = make_uint4(0, 0, 0, 0);
                 as_v[hp] = make_uint4(0, 0, 0, 0);
-                if (ok && g.residual && !g.res_f32) rs_v[hp] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
+                if (ok && g.residual) rs_v[hp] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
                 if (ok && want_aux) as_v[hp] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
             }
         }
@@ -421,8 +409,7 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     MMG_CHECK_ARG(!aux_out || (ldao >= N && ldao % 8 == 0), "mmg_gemm_nt_bf16: bad ldao=%d", ldao);
     GemmNT g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
-    // out_f32: bit 0 = C is fp32, bit 1 = residual is fp32 (ldr in fp32 elements)
-    g.C = C; g.ldc = ldc; g.res_f32 = (out_f32 >> 1) & 1; out_f32 &= 1; g.out_f32 = out_f32; g.bias = bias; g.colscale = colscale;
+    g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.bias = bias; g.colscale = colscale;
     g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = (const bf16_t*)aux_in; g.ldai = ldai;
     g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.out_fp8 = 0; g.alpha_dev = nullptr;
     static const int force_bk = getenv("MMG_GEMM_BK") ? atoi(getenv("MMG_GEMM_BK")) : 0;   // tuning knobs
@@ -447,10 +434,6 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     auto fill = [](long wgs) { return (double)wgs / (double)(cdiv(wgs, 256) * 256L); };
     const double f256 = fill((long)cdiv(M, 256) * cdiv(N, 256)), f128 = fill((long)cdiv(M, 256) * cdiv(N, 128));
     const bool fills = !fill_rule || f256 >= 0.8 * f128;
-    // experiment knob: 256x128 tiles of 8 waves (wave tile 64x64), 32-deep stages in a ring of three, TWO workgroups per CU (4 waves
-    // per SIMD) so that one workgroup's activation epilogue overlaps the other's main loop
-    const int wg2 = getenv("MMG_GEMM_2WG") ? atoi(getenv("MMG_GEMM_2WG")) : 0;
-    if (wg2 && N % 128 == 0 && M >= 4096 && K % 32 == 0) { launch_nt<256, 128, 32, 4, 3>(g, stream); MMG_LAUNCH_CHECK("mmg_gemm_nt_bf16"); return 0; }
     if (use_256 && k64 && N % 256 == 0 && M >= 4096 && K >= use_256 && fills) launch_nt<256, 256, 64, 4, 2>(g, stream);
     else if (use_3wg && !n96 && K % 32 == 0 && K < k3_max) launch_nt<128, 128, 32, 2, 3>(g, stream);
     else if (use_big && k64 && !n96 && M >= 4096 && K >= kbig_min) launch_nt<256, 128, 64, 4, 3>(g, stream);
@@ -479,7 +462,7 @@ MMG_API int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void
     GemmNT g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
     g.C = C; g.ldc = ldc; g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 2; g.bias = bias; g.colscale = colscale;
-    g.residual = (const bf16_t*)residual; g.ldr = ldr; g.res_f32 = 0; g.aux_in = nullptr; g.ldai = 0;
+    g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = nullptr; g.ldai = 0;
     g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.alpha_dev = alpha_dev;
     g.nt_store = (size_t)M * N * (out_kind == 1 ? 4 : out_kind == 2 ? 1 : 2) >= ((size_t)256 << 20);
     static const int tile = getenv("MMG_FP8_TILE") ? atoi(getenv("MMG_FP8_TILE")) : 0;   // tuning: 1 = 256x128, 2 = 128x128

@@ -33,6 +33,7 @@ struct LNArgs {
     int y_fp8;                       // y receives OCP e4m3 bytes (ldy in bytes): operand of the fp8 GEMM path
     int x_f32;                       // x holds fp32 (the text tower keeps its pre-LayerNorm sums in fp32); ldx in elements
     float* yf; int ldyf;             // optional fp32 copy of y (the text tower's residual stream), forward only
+    const float* res; int ldres;     // optional fp32 residual: the row normalised is x + res, and x is OVERWRITTEN with that sum
 };
 
 // 8 consecutive elements of row m of x (bf16 or fp32 storage) as floats
@@ -89,6 +90,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const LNArgs a) {
             const int c = gl + k * G;
             if (c < nchunks) {
                 ln_load_x8(a, m, c, v[k]);
+                if (a.res) {             // (fp32 x only) pre-LayerNorm sum of the text tower, kept for the backward in place of x
+                    const float* rp = a.res + (size_t)m * a.ldres + c * 8;
+                    const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                    v[k][0] += r0.x; v[k][1] += r0.y; v[k][2] += r0.z; v[k][3] += r0.w;
+                    v[k][4] += r1.x; v[k][5] += r1.y; v[k][6] += r1.z; v[k][7] += r1.w;
+                    float* xp = const_cast<float*>(reinterpret_cast<const float*>(a.x)) + (size_t)m * a.ldx + c * 8;
+                    *reinterpret_cast<float4*>(xp) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                    *reinterpret_cast<float4*>(xp + 4) = make_float4(v[k][4], v[k][5], v[k][6], v[k][7]);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += v[k][e];
             }
@@ -261,13 +271,15 @@ MMG_API int mmg_layernorm_fwd(const void* x, int ldx, const float* gamma, const 
 
 // LayerNorm of an fp32 input row (the text tower's pre-LayerNorm sums x + f(x) stay in fp32: bf16 rounding of the residual
 // stream is what owned the end-to-end loss error at BASELINE config C1); y bf16 (GEMM operand) + optional fp32 copy yf.
-MMG_API int mmg_layernorm_fwd_f32(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
-                                  float* yf, int ldyf, float* mean, float* rstd, int M, int C, hipStream_t stream) {
+// With `res` the residual add happens HERE (x <- x + res in place, then normalised): the GEMM that produced x writes plain fp32
+// and its epilogue stays untouched (a runtime fp32-residual branch there cost the big ConvNeXt GEMMs 4-6 %).
+MMG_API int mmg_layernorm_fwd_f32(float* x, int ldx, const float* res, int ldres, const float* gamma, const float* beta, float eps,
+                                  void* y, int ldy, float* yf, int ldyf, float* mean, float* rstd, int M, int C, hipStream_t stream) {
     if (ln_check("mmg_layernorm_fwd_f32", M, C, 0, 0, 0)) return 1;
-    MMG_CHECK_ARG(x && gamma && beta && y && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C && (!yf || (ldyf >= C && ldyf % 4 == 0)),
-                  "mmg_layernorm_fwd_f32: bad pointer or leading dimension");
+    MMG_CHECK_ARG(x && gamma && beta && y && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C && (!yf || (ldyf >= C && ldyf % 4 == 0)) &&
+                      (!res || (ldres >= C && ldres % 4 == 0)), "mmg_layernorm_fwd_f32: bad pointer or leading dimension");
     LNArgs a = {};
-    a.x = reinterpret_cast<const bf16_t*>(x); a.x_f32 = 1; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.x = reinterpret_cast<const bf16_t*>(x); a.x_f32 = 1; a.ldx = ldx; a.res = res; a.ldres = ldres; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.y = (bf16_t*)y; a.ldy = ldy; a.yf = yf; a.ldyf = ldyf; a.mean = mean; a.rstd = rstd; a.M = M; a.C = C;
     if (launch_ln<false>(a, stream)) return 1;
     MMG_LAUNCH_CHECK("mmg_layernorm_fwd_f32");

@@ -30,16 +30,17 @@ def layernorm_fwd(x, gamma, beta, eps, patch_hw=None, want_stats=True):
     return y, mean, rstd
 
 
-def layernorm_fwd_f32(x, gamma, beta, eps, want_stats=True, want_f32=False):
-    """x fp32 [M,C] -> y bf16 [M,C], yf (fp32 copy of y or None), mean, rstd  (text tower: pre-LayerNorm sums stay fp32)."""
+def layernorm_fwd_f32(x, gamma, beta, eps, want_stats=True, want_f32=False, res=None):
+    """x fp32 [M,C] (+ res fp32, added IN PLACE into x first) -> y bf16 [M,C], yf (fp32 copy of y or None), mean, rstd
+    (text tower: residual stream and pre-LayerNorm sums stay fp32)."""
     M, C = x.shape
-    assert x.dtype == torch.float32
+    assert x.dtype == torch.float32 and (res is None or res.dtype == torch.float32)
     y = torch.empty(M, C, device=x.device, dtype=BF16)
     yf = torch.empty(M, C, device=x.device, dtype=torch.float32) if want_f32 else None
     mean = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
-    call("mmg_layernorm_fwd_f32", ptr(x), x.stride(0), ptr(gamma), ptr(beta), float(eps), ptr(y), y.stride(0), ptr(yf),
-         C if want_f32 else 0, ptr(mean), ptr(rstd), M, C, stream())
+    call("mmg_layernorm_fwd_f32", ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(gamma), ptr(beta),
+         float(eps), ptr(y), y.stride(0), ptr(yf), C if want_f32 else 0, ptr(mean), ptr(rstd), M, C, stream())
     return y, yf, mean, rstd
 
 

@@ -23,8 +23,7 @@ def gemm_nt(a, b, out=None, bias=None, colscale=None, residual=None, aux_in=None
     call("mmg_gemm_nt_bf16", ptr(a), _ld(a), ptr(b), _ld(b), ptr(out), _ld(out), M, N, K, ptr(bias), ptr(colscale),
          ptr(residual), _ld(residual) if residual is not None else 0, ptr(aux_in),
          _ld(aux_in) if aux_in is not None else 0, ptr(aux_out), _ld(aux_out) if aux_out is not None else 0, epi,
-         (1 if out.dtype == torch.float32 else 0) | (2 if residual is not None and residual.dtype == torch.float32 else 0),
-         float(alpha), stream())
+         1 if out.dtype == torch.float32 else 0, float(alpha), stream())
     return out
 
 

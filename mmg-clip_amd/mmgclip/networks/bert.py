@@ -201,14 +201,14 @@ class BertTower(nn.Module):
         for i, lyr in enumerate(self.model.encoder.layer):
             qkv = L.gemm_nt(x, wc[f"{i}.wqkv"], bias=wc[f"{i}.bqkv"][:3 * cfg.hidden_size])
             ctx, lse = K.attention_fwd(qkv, mask, B, S, heads, want_lse=save, cu=cu)
-            a = L.gemm_nt(ctx, wc[f"{i}.wo"], bias=lyr.attention.output.dense.bias.data, residual=xf, out_dtype=torch.float32)
+            a = L.gemm_nt(ctx, wc[f"{i}.wo"], bias=lyr.attention.output.dense.bias.data, out_dtype=torch.float32)
             x1, x1f, m1, r1 = K.layernorm_fwd_f32(a, lyr.attention.output.LayerNorm.weight.data, lyr.attention.output.LayerNorm.bias.data,
-                                                  eps, want_stats=save, want_f32=True)
+                                                  eps, want_stats=save, want_f32=True, res=xf)      # a <- a + xf, then LayerNorm
             hpre = torch.empty(x.shape[0], cfg.intermediate_size, device=x.device, dtype=torch.bfloat16) if save else None
             g = L.gemm_nt(x1, wc[f"{i}.wi"], bias=lyr.intermediate.dense.bias.data, epi=L.EPI_GELU, aux_out=hpre)
-            f = L.gemm_nt(g, wc[f"{i}.wf"], bias=lyr.output.dense.bias.data, residual=x1f, out_dtype=torch.float32)
+            f = L.gemm_nt(g, wc[f"{i}.wf"], bias=lyr.output.dense.bias.data, out_dtype=torch.float32)
             x2, x2f, m2, r2 = K.layernorm_fwd_f32(f, lyr.output.LayerNorm.weight.data, lyr.output.LayerNorm.bias.data, eps,
-                                                  want_stats=save, want_f32=True)
+                                                  want_stats=save, want_f32=True, res=x1f)          # f <- f + x1f, then LayerNorm
             if save:
                 saved["layers"].append((x, qkv, ctx, lse, a, m1, r1, x1, hpre, f, m2, r2))
             x, xf = x2, x2f
