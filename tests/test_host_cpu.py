@@ -81,11 +81,18 @@ def test_product_path_fails_loudly_without_gpu():
 
 
 def test_committed_bench_line_follows_the_driver_contract():
-    """profiles/r01_bench_default.json is a line `bench.py` printed on an MI355X: every key of the bench contract is present,
-    the roofline object is self-consistent and names a kernel of the committed rocprof summary."""
+    """profiles/rNN_bench_default.json (every round's) is a line `bench.py` printed on an MI355X: every key of the bench contract is
+    present, the roofline object is self-consistent and names a kernel of the committed rocprof summary of the same round."""
+    import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    b = json.load(open(os.path.join(root, "profiles", "r01_bench_default.json")))
+    lines = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_default.json")))
+    assert lines
+    for path in lines:
+        _check_bench_line(json.load(open(path)), path.replace("_bench_default.json", "_bench_default_kernel_stats.csv"))
+
+
+def _check_bench_line(b, stats_path):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in b, k
@@ -98,8 +105,11 @@ def test_committed_bench_line_follows_the_driver_contract():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
-    stats = open(os.path.join(root, "profiles", "r01_bench_default_kernel_stats.csv")).read()
+    stats = open(stats_path).read()
     assert r["kernel"] in stats
+    if "arithmetic_intensity_flop_per_byte" in r:      # round 2 on: the bound follows the arithmetic intensity, not the larger fraction
+        assert (r["bound"] == "mfma") == (r["arithmetic_intensity_flop_per_byte"] >= r["ridge_flop_per_byte"])
+        assert r["traffic"] is None or str(r.get("traffic_source", "")).startswith("static")
     c = b["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
