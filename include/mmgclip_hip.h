@@ -312,6 +312,30 @@ int mmg_attention_varlen_bwd(const void* qkv, int ld, const int* cu_seqlens, con
                              const void* dctx, int lddc, void* dqkv, int lddq, int B, int S_max, int heads, int Hd,
                              float scale, mmg_stream_t stream);
 
+/* Training-mode dropout of the text tower.  The reference runs HF BertModel under model.train()
+ * (mmgclip/experiments/ClassifierExperiment.py:97 -> mmgclip/networks/encoder.py:156) with hidden_dropout_prob =
+ * attention_probs_dropout_prob = 0.1 (notebooks/bert_experimental.ipynb:609-624).  Masks are counter-based (csrc/dropout.h;
+ * restated in oracle/dropout_oracle.py): element `index` of dropout site `site` is kept, and scaled by 1/(1-p), iff
+ * fmix32(index * 0x9E3779B1 + key(seed, site)) >= floor(p * 2^32) - the backward regenerates the mask from (p, seed, site).
+ *   mmg_attention_dropout_fwd/_bwd: the whole-sequence attention above (S <= 512 forward, <= 256 backward) with the
+ *     probabilities dropped before P V; cu_seqlens != NULL selects the packed layout (then `mask` is unused), else the padded one.
+ *     index = (((first_sequence + b) * heads + h) * 512 + query) * 512 + key  (first_sequence: position of this call's
+ *     sequence 0 in the whole batch, so that micro-batches of one batch draw disjoint masks).
+ *   mmg_dropout_f32 : x fp32 [M,C] <- dropout(x) in place, optional bf16 copy xb.    index = token * C + column, token = rows[m]
+ *   mmg_dropout_bf16: out bf16 [M,C] = dropout(in)  (the same mask on a gradient).    (rows NULL: token = m).
+ * p in [0,1); p = 0 is the identity. */
+int mmg_attention_dropout_fwd(const void* qkv, int ld, const long long* mask, const int* cu_seqlens, void* ctx, int ldc,
+                              float* lse, int B, int S, int heads, int Hd, float scale, float p, unsigned long long seed,
+                              unsigned site, int first_sequence, mmg_stream_t stream);
+int mmg_attention_dropout_bwd(const void* qkv, int ld, const long long* mask, const int* cu_seqlens, const void* ctx, int ldc,
+                              const float* lse, const void* dctx, int lddc, void* dqkv, int lddq, int B, int S, int heads,
+                              int Hd, float scale, float p, unsigned long long seed, unsigned site, int first_sequence,
+                              mmg_stream_t stream);
+int mmg_dropout_f32(float* x, int ldx, void* xb, int ldb, const long long* rows, long long M, int C, float p,
+                    unsigned long long seed, unsigned site, mmg_stream_t stream);
+int mmg_dropout_bf16(const void* in, int ldi, void* out, int ldo, const long long* rows, long long M, int C, float p,
+                     unsigned long long seed, unsigned site, mmg_stream_t stream);
+
 /* out[m,:] = word[ids[m]] + pos[m % S] + type[type_ids[m]] (bf16 tables [V|P|T, H]); HF BertEmbeddings before its
  * LayerNorm (mmgclip/networks/encoder.py:156). */
 int mmg_bert_embed_fwd(const long long* ids, const long long* type_ids, const void* word, const void* pos,

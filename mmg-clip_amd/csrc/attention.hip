@@ -10,6 +10,7 @@
 // The backward recomputes P from the saved log-sum-exp (no S x S tensor in HBM), pass 1 with a query row per lane
 // (dQ), pass 2 with a key per lane (dK, dV); every output row has exactly one writer, so there are no atomics.
 #include "common.h"
+#include "dropout.h"
 
 #define ATT_D 64
 #define ATT_NEG (-1.0e30f)
@@ -73,10 +74,20 @@ struct AttArgs {
     // backward
     const bf16_t* dctx; int lddc;       // [B*S, Hd]
     bf16_t* dqkv; int lddq;             // [B*S, 3*Hd]
+    DropArgs drop;                      // attention-probability dropout (DROP instantiations of the whole-sequence kernels only)
+    int bh0;                            // (sequence, head) index of blockIdx.x = 0 in the mask index (micro-batches of one batch)
 };
 
+// keep / scale of probability (sequence-head bh, query q, key k): see dropout.h
+__device__ __forceinline__ float att_drop(float v, int bh, int q, int k, const DropArgs d) {
+    const unsigned idx = ((unsigned)bh * 512u + (unsigned)q) * 512u + (unsigned)k;
+    return mmg_drop_bits(idx, d.key) >= d.thresh ? v * d.scale : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
-template <int NT>   // NT >= S_pad / 16
+// DROP: HF's attention_probs_dropout - the normalised probabilities are masked and rescaled before the P V product (the row
+// log-sum-exp is that of the undropped softmax).
+template <int NT, bool DROP>   // NT >= S_pad / 16
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -140,7 +151,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttArgs a) {
 #pragma unroll
         for (int c = 0; c < NT / 2; ++c) {
             if (2 * c < ntile) {
-                const bf16x8 pf = pack_frag(sc[2 * c] * inv, sc[2 * c + 1] * inv);
+                f32x4 p0 = sc[2 * c] * inv, p1 = sc[2 * c + 1] * inv;
+                if constexpr (DROP) {            // element r of tile t: key 16 t + 4 g + r, query q0 + li
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        p0[r] = att_drop(p0[r], blockIdx.x + a.bh0, q0 + li, 32 * c + 4 * g + r, a.drop);
+                        p1[r] = att_drop(p1[r], blockIdx.x + a.bh0, q0 + li, 32 * c + 16 + 4 * g + r, a.drop);
+                    }
+                }
+                const bf16x8 pf = pack_frag(p0, p1);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_tr_frag(Vs, c * 32, dt, lane), pf, o[dt], 0, 0, 0);
@@ -163,6 +182,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttArgs a) {
 // ---------------------------------------------------------------------------------------------
 // backward: dqkv <- (dQ | dK | dV) of this head.  S_pad <= 256.
 // ---------------------------------------------------------------------------------------------
+// DROP: with P~ = mask P / (1 - p) the forward is O = P~ V, so dV = P~^T dO, dP = mask (dO V^T) / (1 - p) and
+// dS = P (dP - delta) with delta = rowsum(dO O) unchanged (sum_k P dP = sum_k P~ (dO V^T) = dO . O).
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int img = a.S_pad * 128;
@@ -233,7 +255,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __expf(s[r] * a.scale + mk[r] - lq);
-                    ds[t][r] = p * (dp[r] - dq_) * a.scale;
+                    const float dpr = DROP ? att_drop(dp[r], blockIdx.x + a.bh0, q0 + li, k0 + 4 * g + r, a.drop) : dp[r];
+                    ds[t][r] = p * (dpr - dq_) * a.scale;
                 }
             }
             const bf16x8 dsf = pack_frag(ds[0], ds[1]);
@@ -277,8 +300,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __expf(s[r] * a.scale + mk - lq[r]);
-                    pp[t][r] = p;
-                    ds[t][r] = p * (dp[r] - dl[r]) * a.scale;
+                    pp[t][r] = DROP ? att_drop(p, blockIdx.x + a.bh0, q0 + 4 * g + r, k0 + li, a.drop) : p;
+                    const float dpr = DROP ? att_drop(dp[r], blockIdx.x + a.bh0, q0 + 4 * g + r, k0 + li, a.drop) : dp[r];
+                    ds[t][r] = p * (dpr - dl[r]) * a.scale;
                 }
             }
             const bf16x8 pf = pack_frag(pp[0], pp[1]), dsf = pack_frag(ds[0], ds[1]);
@@ -324,8 +348,8 @@ MMG_API int mmg_attention_fwd(const void* qkv, int ld, const long long* mask, vo
     const int nt = a.S_pad / 16;
 #define ATT_FWD(NT)                                                                                   \
     do {                                                                                              \
-        mmg_allow_lds(attn_fwd_kernel<NT>, shm);                                                      \
-        hipLaunchKernelGGL(attn_fwd_kernel<NT>, grid, dim3(256), shm, stream, a);                     \
+        mmg_allow_lds(attn_fwd_kernel<NT, false>, shm);                                               \
+        hipLaunchKernelGGL((attn_fwd_kernel<NT, false>), grid, dim3(256), shm, stream, a);            \
     } while (0)
     if (nt <= 6) ATT_FWD(6);
     else if (nt <= 8) ATT_FWD(8);
@@ -348,8 +372,8 @@ MMG_API int mmg_attention_bwd(const void* qkv, int ld, const long long* mask, co
     a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
     a.dctx = (const bf16_t*)dctx; a.lddc = lddc; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
     const size_t shm = (size_t)4 * a.S_pad * 128 + 3 * a.S_pad * 4;
-    mmg_allow_lds(attn_bwd_kernel, shm);
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), shm, stream, a);
+    mmg_allow_lds(attn_bwd_kernel<false>, shm);
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * heads), dim3(256), shm, stream, a);
     MMG_LAUNCH_CHECK("mmg_attention_bwd");
     return 0;
 }
@@ -370,8 +394,8 @@ MMG_API int mmg_attention_varlen_fwd(const void* qkv, int ld, const int* cu_seql
     const int nt = a.S_pad / 16;
 #define ATT_FWD(NT)                                                                                   \
     do {                                                                                              \
-        mmg_allow_lds(attn_fwd_kernel<NT>, shm);                                                      \
-        hipLaunchKernelGGL(attn_fwd_kernel<NT>, grid, dim3(256), shm, stream, a);                     \
+        mmg_allow_lds(attn_fwd_kernel<NT, false>, shm);                                               \
+        hipLaunchKernelGGL((attn_fwd_kernel<NT, false>), grid, dim3(256), shm, stream, a);            \
     } while (0)
     if (nt <= 6) ATT_FWD(6);
     else if (nt <= 8) ATT_FWD(8);
@@ -393,9 +417,70 @@ MMG_API int mmg_attention_varlen_bwd(const void* qkv, int ld, const int* cu_seql
     a.S = S_max; a.S_pad = cdiv(S_max, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
     a.dctx = (const bf16_t*)dctx; a.lddc = lddc; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
     const size_t shm = (size_t)4 * a.S_pad * 128 + 3 * a.S_pad * 4;
-    mmg_allow_lds(attn_bwd_kernel, shm);
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), shm, stream, a);
+    mmg_allow_lds(attn_bwd_kernel<false>, shm);
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * heads), dim3(256), shm, stream, a);
     MMG_LAUNCH_CHECK("mmg_attention_varlen_bwd");
+    return 0;
+}
+
+// Training-mode attention with dropout of the probabilities (dropout.h; HF BertSelfAttention.dropout, live in the reference's
+// training loop).  One entry point for both layouts: cu_seqlens != nullptr selects the packed layout (mask unused), otherwise the
+// padded one with its key mask.  `site` separates the layers' masks; the backward must be given the forward's (p, seed, site).
+static int att_drop_args(const char* who, float p, unsigned long long seed, unsigned site, DropArgs& d) {
+    MMG_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout probability %g must be in [0, 1)", who, (double)p);
+    d.key = mmg_drop_key(seed, site);
+    d.thresh = mmg_drop_threshold(p);
+    d.scale = 1.0f / (1.0f - p);
+    return 0;
+}
+
+MMG_API int mmg_attention_dropout_fwd(const void* qkv, int ld, const long long* mask, const int* cu_seqlens, void* ctx, int ldc,
+                                      float* lse, int B, int S, int heads, int Hd, float scale, float p, unsigned long long seed,
+                                      unsigned site, int first_sequence, hipStream_t stream) {
+    if (att_check("mmg_attention_dropout_fwd", B, S, heads, Hd, ld, 512)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && ldc >= Hd && ldc % 8 == 0, "mmg_attention_dropout_fwd: bad ctx");
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.cu = cu_seqlens; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = lse;
+    a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    if (att_drop_args("mmg_attention_dropout_fwd", p, seed, site, a.drop)) return 1;
+    MMG_CHECK_ARG(first_sequence >= 0, "mmg_attention_dropout_fwd: first_sequence %d", first_sequence);
+    a.bh0 = first_sequence * heads;
+    const size_t shm = (size_t)2 * a.S_pad * 128 + a.S_pad * 4;
+    const dim3 grid(B * heads);
+    const int nt = a.S_pad / 16;
+#define ATT_FWD(NT)                                                                                   \
+    do {                                                                                              \
+        mmg_allow_lds(attn_fwd_kernel<NT, true>, shm);                                                \
+        hipLaunchKernelGGL((attn_fwd_kernel<NT, true>), grid, dim3(256), shm, stream, a);             \
+    } while (0)
+    if (nt <= 6) ATT_FWD(6);
+    else if (nt <= 8) ATT_FWD(8);
+    else if (nt <= 16) ATT_FWD(16);
+    else ATT_FWD(32);
+#undef ATT_FWD
+    MMG_LAUNCH_CHECK("mmg_attention_dropout_fwd");
+    return 0;
+}
+
+MMG_API int mmg_attention_dropout_bwd(const void* qkv, int ld, const long long* mask, const int* cu_seqlens, const void* ctx,
+                                      int ldc, const float* lse, const void* dctx, int lddc, void* dqkv, int lddq, int B, int S,
+                                      int heads, int Hd, float scale, float p, unsigned long long seed, unsigned site,
+                                      int first_sequence, hipStream_t stream) {
+    if (att_check("mmg_attention_dropout_bwd", B, S, heads, Hd, ld, 256)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && ldc >= Hd && lddc >= Hd && lddq >= 3 * Hd && ldc % 8 == 0 &&
+                      lddc % 8 == 0 && lddq % 8 == 0, "mmg_attention_dropout_bwd: bad pointer or leading dimension");
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.cu = cu_seqlens; a.ctx = (bf16_t*)ctx; a.ldc = ldc;
+    a.lse = const_cast<float*>(lse);
+    a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    a.dctx = (const bf16_t*)dctx; a.lddc = lddc; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
+    if (att_drop_args("mmg_attention_dropout_bwd", p, seed, site, a.drop)) return 1;
+    MMG_CHECK_ARG(first_sequence >= 0, "mmg_attention_dropout_bwd: first_sequence %d", first_sequence);
+    a.bh0 = first_sequence * heads;
+    const size_t shm = (size_t)4 * a.S_pad * 128 + 3 * a.S_pad * 4;
+    mmg_allow_lds(attn_bwd_kernel<true>, shm);
+    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * heads), dim3(256), shm, stream, a);
+    MMG_LAUNCH_CHECK("mmg_attention_dropout_bwd");
     return 0;
 }
 

@@ -96,6 +96,23 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const PackArgs a) {
     }
 }
 
+#ifdef MLP_PROBE
+// Debug builds only (tools/mlp_probe.py): per-phase shader-clock totals of the forward, summed over waves.
+//   [0] whole tile loop  [1] chunk-top wait + barrier  [2] GEMM 1  [3] GELU  [4] GEMM 2  [5] waves
+__device__ unsigned long long g_mlp_probe[8];
+MMG_API int mmg_debug_mlp_probe(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mlp_probe), 64) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_probe), z, 64) != hipSuccess) return 1;
+    return 0;
+}
+#define PROBE_T(var) const long long var = __builtin_readcyclecounter()
+#define PROBE_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define PROBE_T(var)
+#define PROBE_ADD(acc, a, b)
+#endif
+
 // ---- forward ---------------------------------------------------------------------------------------------------------
 template <int C, bool SAVE>
 __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_kernel(const MlpFwd p) {
@@ -128,6 +145,10 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
     for (int i = tid; i < 4 * C; i += MLP_THREADS) s_b1[i] = p.b1[i];
     __syncthreads();
 
+#ifdef MLP_PROBE
+    long long pr_wait = 0, pr_g1 = 0, pr_gelu = 0, pr_g2 = 0;
+#endif
+    PROBE_T(pr_start);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const long row0 = (long)tile * MLP_BM + wave * (16 * MT) + li;          // + 16*mi
         // ---- rows of d -> LayerNorm -> bf16 B-operand fragments ---------------------------------------------------------
@@ -186,13 +207,19 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
 
         // ---- hidden chunks ---------------------------------------------------------------------------------------------
         for (int ch = 0; ch < NCH; ++ch) {
+            PROBE_T(pr_a);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            PROBE_T(pr_b);
+            PROBE_ADD(pr_wait, pr_a, pr_b);
             if (ch + 1 < NCH) stage((ch + 1) & 1, ch + 1);
             else if (tile + (int)gridDim.x < p.ntiles) stage(0, 0);
             const char* wb = smem + (ch & 1) * CHUNK;
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
+#if defined(MLP_PROBE) && MLP_PROBE >= 2
+                PROBE_T(pr_c);
+#endif
                 // accumulators start from the bias (lane owns 4 consecutive hidden columns of its rows)
                 const int n0 = ch * NC + sub * 32 + 8 * lg;        // this lane's 8 consecutive hidden units
                 const f32x4 bia0 = *reinterpret_cast<const f32x4*>(s_b1 + n0);
@@ -210,6 +237,11 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
                             hacc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mi][ks], hacc[mi][tt], 0, 0, 0);
                     }
                 }
+#if defined(MLP_PROBE) && MLP_PROBE >= 2
+                asm volatile("" : "+v"(hacc[0][0]), "+v"(hacc[MT - 1][1]));
+                PROBE_T(pr_d);
+                PROBE_ADD(pr_g1, pr_c, pr_d);
+#endif
                 bf16x8 gf[MT];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
@@ -225,6 +257,11 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
                     gf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{pack2bf(gelu_bf16(h0[0]), gelu_bf16(h0[1])), pack2bf(gelu_bf16(h0[2]), gelu_bf16(h0[3])),
                                                                  pack2bf(gelu_bf16(h1[0]), gelu_bf16(h1[1])), pack2bf(gelu_bf16(h1[2]), gelu_bf16(h1[3]))}));
                 }
+#if defined(MLP_PROBE) && MLP_PROBE >= 2
+                asm volatile("" : "+v"(gf[0]), "+v"(gf[MT - 1]));
+                PROBE_T(pr_e);
+                PROBE_ADD(pr_gelu, pr_d, pr_e);
+#endif
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + PART + (((4 * sub + lg) * C + ct * 16 + li) << 4));
@@ -232,6 +269,11 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
                     for (int mi = 0; mi < MT; ++mi)
                         yacc[mi][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf[mi], yacc[mi][ct], 0, 0, 0);
                 }
+#if defined(MLP_PROBE) && MLP_PROBE >= 2
+                asm volatile("" : "+v"(yacc[0][0]), "+v"(yacc[MT - 1][CT - 1]));
+                PROBE_T(pr_f);
+                PROBE_ADD(pr_g2, pr_e, pr_f);
+#endif
             }
         }
 
@@ -262,6 +304,14 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
             }
         }
     }
+#ifdef MLP_PROBE
+    PROBE_T(pr_end);
+    if (lane == 0) {
+        atomicAdd(&g_mlp_probe[0], (unsigned long long)(pr_end - pr_start)); atomicAdd(&g_mlp_probe[1], (unsigned long long)pr_wait);
+        atomicAdd(&g_mlp_probe[2], (unsigned long long)pr_g1); atomicAdd(&g_mlp_probe[3], (unsigned long long)pr_gelu);
+        atomicAdd(&g_mlp_probe[4], (unsigned long long)pr_g2); atomicAdd(&g_mlp_probe[5], 1ull);
+    }
+#endif
 }
 
 // ---- backward (data path) ---------------------------------------------------------------------------------------------

@@ -18,6 +18,8 @@ _CTYPES = {
     "int": ctypes.c_int,
     "float": ctypes.c_float,
     "long long": ctypes.c_longlong,
+    "unsigned long long": ctypes.c_ulonglong,
+    "unsigned": ctypes.c_uint,
     "size_t": ctypes.c_size_t,
     "mmg_stream_t": ctypes.c_void_p,
 }

@@ -220,6 +220,45 @@ def attention_fwd(qkv, mask, B, S, heads, want_lse=True, force_long=False, cu=No
     return ctx, lse
 
 
+def attention_dropout_fwd(qkv, mask, B, S, heads, p, seed, site, want_lse=True, cu=None, first_sequence=0):
+    """attention_fwd with HF's attention_probs_dropout (csrc/dropout.h): S <= 512; cu selects the packed layout."""
+    Hd = heads * 64
+    ctx = torch.empty(qkv.shape[0], Hd, device=qkv.device, dtype=BF16)
+    lse = torch.empty(B, heads, S, device=qkv.device, dtype=torch.float32) if want_lse else None
+    call("mmg_attention_dropout_fwd", ptr(qkv), qkv.stride(0), ptr(mask) if cu is None else None, ptr(cu), ptr(ctx), Hd, ptr(lse),
+         B, S, heads, Hd, 0.125, float(p), int(seed), int(site), int(first_sequence), stream())
+    return ctx, lse
+
+
+def attention_dropout_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, p, seed, site, cu=None, first_sequence=0):
+    """Backward of attention_dropout_fwd (same p, seed, site): S <= 256."""
+    Hd = heads * 64
+    dqkv = torch.empty(qkv.shape[0], 3 * Hd, device=qkv.device, dtype=BF16)
+    call("mmg_attention_dropout_bwd", ptr(qkv), qkv.stride(0), ptr(mask) if cu is None else None, ptr(cu), ptr(ctx), ctx.stride(0),
+         ptr(lse), ptr(dctx), dctx.stride(0), ptr(dqkv), dqkv.stride(0), B, S, heads, Hd, 0.125, float(p), int(seed), int(site),
+         int(first_sequence), stream())
+    return dqkv
+
+
+def dropout_f32_(x, p, seed, site, rows=None, want_bf16=False):
+    """x fp32 [M,C] <- dropout(x) in place (mask index token * C + column, token = rows[m] or m); -> bf16 copy or None."""
+    M, C = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    xb = torch.empty(M, C, device=x.device, dtype=BF16) if want_bf16 else None
+    call("mmg_dropout_f32", ptr(x), x.stride(0), ptr(xb), C if want_bf16 else 0, ptr(rows), M, C, float(p), int(seed), int(site),
+         stream())
+    return xb
+
+
+def dropout_bf16(x, p, seed, site, rows=None):
+    """dropout(x) for a bf16 [M,C] tensor (the forward's mask applied to a gradient)."""
+    M, C = x.shape
+    assert x.dtype == BF16 and x.stride(1) == 1
+    out = torch.empty(M, C, device=x.device, dtype=BF16)
+    call("mmg_dropout_bf16", ptr(x), x.stride(0), ptr(out), C, ptr(rows), M, C, float(p), int(seed), int(site), stream())
+    return out
+
+
 def attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, out=None, force_long=False, cu=None):
     Hd = heads * 64
     dqkv = out if out is not None else torch.empty(qkv.shape[0], 3 * Hd, device=qkv.device, dtype=BF16)

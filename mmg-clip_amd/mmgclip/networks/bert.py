@@ -4,8 +4,10 @@ Reference: `BertEncoder` wraps `AutoModel.from_pretrained(<name>)` and returns `
 (mmgclip/networks/encoder.py:131-156); architecture values from notebooks/bert_experimental.ipynb:609-624
 (vocab 28996, hidden 768, 12 layers x 12 heads, FFN 3072, 512 positions, LayerNorm eps 1e-12, erf-GELU, post-LN).
 The reference freezes every BERT parameter (encoder.py:141-142); `freeze=False` enables the north star's fine-tuning.
-Dropout (p = 0.1 in the HF config, live because the reference calls model.train()) is NOT applied here: parity is
-defined for eval()/p = 0 (SURVEY.md §0, §7 "Hard parts").
+Dropout (p = 0.1 in the HF config, live because the reference calls model.train(), ClassifierExperiment.py:97) is applied in
+training mode at HF's four positions with counter-based masks (csrc/dropout.h): the backward regenerates them from the step's
+seed, and the oracle restates them (oracle/dropout_oracle.py), so parity holds mask for mask.  eval() / `dropout=False` / p = 0
+give the deterministic tower.
 
 Device layout: hidden states bf16 [B*S, 768]; Q, K, V come from ONE fused GEMM ([2304, 768] weight = the three HF
 matrices stacked, contiguous in the parameter arena so its gradient needs no scatter).
@@ -26,11 +28,13 @@ class BertConfigLite:
 
     def __init__(self, vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                  intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
-                 initializer_range=0.02, **_):
+                 initializer_range=0.02, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, **_):
         self.vocab_size, self.hidden_size = vocab_size, hidden_size
         self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
         self.intermediate_size, self.max_position_embeddings = intermediate_size, max_position_embeddings
         self.type_vocab_size, self.layer_norm_eps, self.initializer_range = type_vocab_size, layer_norm_eps, initializer_range
+        self.hidden_dropout_prob, self.attention_probs_dropout_prob = float(hidden_dropout_prob), float(attention_probs_dropout_prob)
+        assert 0.0 <= self.hidden_dropout_prob < 1.0 and 0.0 <= self.attention_probs_dropout_prob < 1.0
         assert hidden_size == 64 * num_attention_heads, "the attention kernel is specialised for head_dim 64"
 
 
@@ -75,9 +79,11 @@ def _hf_layout(cfg):
 
 
 class BertTower(nn.Module):
-    def __init__(self, config=None, micro_batch=4096):
+    def __init__(self, config=None, micro_batch=4096, dropout=True):
         super().__init__()
         self.config = config or BertConfigLite()
+        self.dropout = bool(dropout)          # training-mode dropout on (the reference's behaviour); eval() turns it off as in HF
+        self.next_dropout_seed = None         # tests: force the seed of the next training-mode forward
         self.model = _hf_layout(self.config)
         self.model.config = self.config
         self.model_output_dimension = self.config.hidden_size
@@ -182,8 +188,43 @@ class BertTower(nn.Module):
         cu[1:] = torch.tensor(sl, dtype=torch.int32).cumsum(0)
         return rows.to(device), cu.to(device)
 
+    # ---- dropout -------------------------------------------------------------------------------------------------
+    # sites of one step's masks (oracle/dropout_oracle.py uses the same numbering)
+    SITE_EMBEDDINGS = 0
+
+    @staticmethod
+    def _site(layer, which):
+        """which: 1 attention probabilities, 2 attention output dense, 3 FFN output dense."""
+        return 4 * layer + which
+
+    def _draw_dropout(self):
+        """(p_hidden, p_attention, seed) for this forward, or None (eval mode, dropout=False, both p = 0).  The seed comes from
+        torch's CPU generator, so torch.manual_seed makes a run reproducible and ranks seeded differently draw different masks."""
+        cfg = self.config
+        if not (self.training and self.dropout) or (cfg.hidden_dropout_prob == 0.0 and cfg.attention_probs_dropout_prob == 0.0):
+            return None
+        if os.environ.get("MMG_BERT_DROPOUT", "1") == "0":        # operational off-switch (deterministic runs, the parity tests)
+            return None
+        if self.next_dropout_seed is not None:
+            seed, self.next_dropout_seed = int(self.next_dropout_seed), None
+        else:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob, seed
+
+    _warned_long_attention_dropout = False
+
+    def _attention_dropout_ok(self, S):
+        if S <= 256:
+            return True
+        if not BertTower._warned_long_attention_dropout:
+            import warnings
+            warnings.warn(f"attention-probability dropout is implemented for S <= 256 (got S = {S}): skipped; the hidden-state "
+                          "dropouts stay on")
+            BertTower._warned_long_attention_dropout = True
+        return False
+
     # ---- one micro-batch ---------------------------------------------------------------------------------------
-    def _forward_mb(self, ids, tt, mask, save, pack=None):
+    def _forward_mb(self, ids, tt, mask, save, pack=None, drop=None, b0=0):
         cfg, wc = self.config, self._wc
         B, S = ids.shape
         heads, eps = cfg.num_attention_heads, cfg.layer_norm_eps
@@ -192,21 +233,40 @@ class BertTower(nn.Module):
         rows, cu = pack if pack is not None else (None, None)
         if rows is not None:
             emb = emb.index_select(0, rows)                  # [T, H]: the valid tokens, sequence after sequence
+        tok = None                                           # token id (b * S + s in the whole batch) of every row, for the masks
+        p_h = p_a = 0.0
+        if drop is not None:
+            p_h, p_a, seed = drop
+            if not self._attention_dropout_ok(S):
+                p_a = 0.0
+            if rows is not None or b0 > 0:
+                tok = (rows if rows is not None else torch.arange(B * S, device=ids.device)) + b0 * S
         # The residual stream and the pre-LayerNorm sums x + sublayer(x) are kept in fp32 (`xf`, `a`, `f`); every GEMM still reads a
         # bf16 copy of the stream (`x`).  Measured at BASELINE config C1 (tests/test_c1_gpu.py): with a bf16 stream the text tower
         # owned the end-to-end loss error (1e-3 relative, the north star's bar); BERT is 5 % of the step, so the fp32 rows are free.
         x, xf, mean, rstd = K.layernorm_fwd_f32(emb.float(), e.LayerNorm.weight.data, e.LayerNorm.bias.data, eps, want_stats=save,
                                                 want_f32=True)
-        saved = {"emb": (emb, mean, rstd), "layers": [], "shape": (B, S), "tok": (ids, tt, mask), "pack": pack} if save else None
+        if p_h > 0:                                          # HF BertEmbeddings: dropout after the LayerNorm
+            x = K.dropout_f32_(xf, p_h, seed, self.SITE_EMBEDDINGS, rows=tok, want_bf16=True)
+        saved = {"emb": (emb, mean, rstd), "layers": [], "shape": (B, S), "tok": (ids, tt, mask), "pack": pack,
+                 "drop": (p_h, p_a, seed, tok, b0) if drop is not None else None} if save else None
         for i, lyr in enumerate(self.model.encoder.layer):
             qkv = L.gemm_nt(x, wc[f"{i}.wqkv"], bias=wc[f"{i}.bqkv"][:3 * cfg.hidden_size])
-            ctx, lse = K.attention_fwd(qkv, mask, B, S, heads, want_lse=save, cu=cu)
+            if p_a > 0:                                      # HF BertSelfAttention: dropout on the probabilities
+                ctx, lse = K.attention_dropout_fwd(qkv, mask, B, S, heads, p_a, seed, self._site(i, 1), want_lse=save, cu=cu,
+                                                   first_sequence=b0)
+            else:
+                ctx, lse = K.attention_fwd(qkv, mask, B, S, heads, want_lse=save, cu=cu)
             a = L.gemm_nt(ctx, wc[f"{i}.wo"], bias=lyr.attention.output.dense.bias.data, out_dtype=torch.float32)
+            if p_h > 0:                                      # HF BertSelfOutput: dropout(dense(ctx)) + residual
+                K.dropout_f32_(a, p_h, seed, self._site(i, 2), rows=tok)
             x1, x1f, m1, r1 = K.layernorm_fwd_f32(a, lyr.attention.output.LayerNorm.weight.data, lyr.attention.output.LayerNorm.bias.data,
                                                   eps, want_stats=save, want_f32=True, res=xf)      # a <- a + xf, then LayerNorm
             hpre = torch.empty(x.shape[0], cfg.intermediate_size, device=x.device, dtype=torch.bfloat16) if save else None
             g = L.gemm_nt(x1, wc[f"{i}.wi"], bias=lyr.intermediate.dense.bias.data, epi=L.EPI_GELU, aux_out=hpre)
             f = L.gemm_nt(g, wc[f"{i}.wf"], bias=lyr.output.dense.bias.data, out_dtype=torch.float32)
+            if p_h > 0:                                      # HF BertOutput: dropout(dense(g)) + residual
+                K.dropout_f32_(f, p_h, seed, self._site(i, 3), rows=tok)
             x2, x2f, m2, r2 = K.layernorm_fwd_f32(f, lyr.output.LayerNorm.weight.data, lyr.output.LayerNorm.bias.data, eps,
                                                   want_stats=save, want_f32=True, res=x1f)          # f <- f + x1f, then LayerNorm
             if save:
@@ -227,25 +287,36 @@ class BertTower(nn.Module):
         if rows is not None:
             dx = dx.index_select(0, rows)
         heads, H = cfg.num_attention_heads, cfg.hidden_size
+        p_h, p_a, seed, tok, b0 = saved["drop"] if saved.get("drop") is not None else (0.0, 0.0, 0, None, 0)
+        # a dropped sub-layer output y~ = mask y / (1 - p) sits next to the residual: the LayerNorm backward's gradient goes to the
+        # residual path as it is and to the sub-layer's GEMMs through the same mask
+        masked = (lambda t, site: K.dropout_bf16(t, p_h, seed, site, rows=tok)) if p_h > 0 else (lambda t, site: t)
         for i in range(cfg.num_hidden_layers - 1, -1, -1):
             lyr = self.model.encoder.layer[i]
             p = f"encoder.layer.{i}."
             x, qkv, ctx, lse, a, m1, r1, x1, hpre, f, m2, r2 = saved["layers"][i]
             df = K.layernorm_bwd_f32(dx, f, m2, r2, lyr.output.LayerNorm.weight.data, A.g(p + "output.LayerNorm.weight"),
                                      A.g(p + "output.LayerNorm.bias"))
+            dfm = masked(df, self._site(i, 3))
             g = torch.empty_like(hpre)                     # GELU(hpre), rebuilt by the same epilogue that applies GELU'
-            dh = L.gemm_nt(df, wc[f"{i}.wft"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
-            L.gemm_tn_acc(df, g, A.g(p + "output.dense.weight"), colsum=A.g(p + "output.dense.bias"))
-            del g
+            dh = L.gemm_nt(dfm, wc[f"{i}.wft"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
+            L.gemm_tn_acc(dfm, g, A.g(p + "output.dense.weight"), colsum=A.g(p + "output.dense.bias"))
+            del g, dfm
             L.gemm_tn_acc(dh, x1, A.g(p + "intermediate.dense.weight"), colsum=A.g(p + "intermediate.dense.bias"))
             dx1 = L.gemm_nt(dh, wc[f"{i}.wit"], residual=df)          # + residual path of the FFN block
             del dh, df
             da = K.layernorm_bwd_f32(dx1, a, m1, r1, lyr.attention.output.LayerNorm.weight.data,
                                      A.g(p + "attention.output.LayerNorm.weight"), A.g(p + "attention.output.LayerNorm.bias"))
             del dx1
-            L.gemm_tn_acc(da, ctx, A.g(p + "attention.output.dense.weight"), colsum=A.g(p + "attention.output.dense.bias"))
-            dctx = L.gemm_nt(da, wc[f"{i}.wot"])
-            dqkv = K.attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, cu=cu)
+            dam = masked(da, self._site(i, 2))
+            L.gemm_tn_acc(dam, ctx, A.g(p + "attention.output.dense.weight"), colsum=A.g(p + "attention.output.dense.bias"))
+            dctx = L.gemm_nt(dam, wc[f"{i}.wot"])
+            del dam
+            if p_a > 0:
+                dqkv = K.attention_dropout_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, p_a, seed, self._site(i, 1), cu=cu,
+                                               first_sequence=b0)
+            else:
+                dqkv = K.attention_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, cu=cu)
             del dctx
             gw = A.gspan(p + "attention.self.query.weight", p + "attention.self.value.weight")[:3 * H * H].view(3 * H, H)
             gb = A.gspan(p + "attention.self.query.bias", p + "attention.self.value.bias")[:3 * H]
@@ -255,6 +326,7 @@ class BertTower(nn.Module):
             saved["layers"][i] = None
         emb, mean, rstd = saved["emb"]
         e = self.model.embeddings
+        dx = masked(dx, self.SITE_EMBEDDINGS)
         demb = K.layernorm_bwd(dx, emb, mean, rstd, e.LayerNorm.weight.data, A.g("embeddings.LayerNorm.weight"),
                                A.g("embeddings.LayerNorm.bias"))
         if rows is not None:
@@ -291,11 +363,12 @@ class _BertFn(torch.autograd.Function):
         save = anchor is not None
         outs, saved = [], []
         mb = tower.micro_batch
+        drop = tower._draw_dropout()
         for i in range(0, ids.shape[0], mb):
             sl = slice(i, i + mb)
             pack = tower._packing(lens, i, min(i + mb, ids.shape[0]), ids.shape[1], ids.device)
             h, sv = tower._forward_mb(ids[sl], tt[sl] if tt is not None else None, mask[sl] if mask is not None else None, save,
-                                      pack)
+                                      pack, drop, i)
             outs.append(h)
             saved.append(sv)
         ctx.tower, ctx.saved_mb = tower, saved if save else None
@@ -337,6 +410,6 @@ def hf_config_dict(cfg):
     return dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
                 num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
                 max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
-                layer_norm_eps=cfg.layer_norm_eps, hidden_act="gelu", hidden_dropout_prob=0.0,
-                attention_probs_dropout_prob=0.0, initializer_range=cfg.initializer_range, pad_token_id=0,
+                layer_norm_eps=cfg.layer_norm_eps, hidden_act="gelu", hidden_dropout_prob=cfg.hidden_dropout_prob,
+                attention_probs_dropout_prob=cfg.attention_probs_dropout_prob, initializer_range=cfg.initializer_range, pad_token_id=0,
                 position_embedding_type="absolute", model_type="bert")

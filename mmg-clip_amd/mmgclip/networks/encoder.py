@@ -127,11 +127,12 @@ class BertEncoder(BertTower):
     """`BertEncoder(pretrained=<local dir | hub name>)`; attrs `model`, `model_output_dimension` (encoder.py:131-144).
 
     `pretrained` may be a local directory holding `config.json` and `model.safetensors` / `pytorch_model.bin`
-    (HF layout).  A hub name cannot be fetched offline: it falls back to a seeded random initialisation of the
+    (HF layout).  `dropout` (additive knob, networks.text_encoder.dropout, default true): HF's training-mode dropout, as the
+    reference runs it (model.train(), ClassifierExperiment.py:97); eval() switches it off.  A hub name cannot be fetched offline: it falls back to a seeded random initialisation of the
     Bio_ClinicalBERT architecture only when `random_init=True` (or MMGCLIP_RANDOM_INIT=1), otherwise raises.
     """
 
-    def __init__(self, pretrained=None, freeze=True, random_init=False, config=None, micro_batch=4096):
+    def __init__(self, pretrained=None, freeze=True, random_init=False, config=None, micro_batch=4096, dropout=True):
         cfg, sd = config, None
         if isinstance(pretrained, str) and os.path.isdir(pretrained):
             with open(os.path.join(pretrained, "config.json")) as fh:
@@ -145,7 +146,7 @@ class BertEncoder(BertTower):
         elif not (random_init or os.environ.get("MMGCLIP_RANDOM_INIT") == "1"):
             raise OSError(f"cannot fetch '{pretrained}' (no network): pass a local Hugging Face directory, or set "
                           f"networks.text_encoder.random_init / MMGCLIP_RANDOM_INIT=1 for seeded random weights")
-        super().__init__(cfg or BertConfigLite(), micro_batch=micro_batch)
+        super().__init__(cfg or BertConfigLite(), micro_batch=micro_batch, dropout=dropout)
         logger.info(f"Initializing pretrained `{pretrained}` as the text encoder and tokenizer.")
         if sd is not None:
             sd = {k[len("bert."):] if k.startswith("bert.") else k: v for k, v in sd.items()}

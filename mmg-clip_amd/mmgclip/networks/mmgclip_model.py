@@ -59,7 +59,7 @@ class MMGCLIP(nn.Module):
         te = self.config.networks.text_encoder
         self.text_encoder = getNetworkClass(te.name)(
             pretrained=self.config.tokenizer.config.tokenizer_name, freeze=_get(te, "freeze", True),
-            random_init=_get(te, "random_init", False)).to(self.device)
+            random_init=_get(te, "random_init", False), dropout=bool(_get(te, "dropout", True))).to(self.device)
 
         if self.config.projection.config.projection_name != "ZeroProjection":
             head_cls = get_projection_head(self.config.projection.config.projection_name)

@@ -86,8 +86,11 @@ def convnext_forward(sd, images, depths=(3, 3, 9, 3), scale16=True, prefix="feat
     return F.adaptive_avg_pool2d(x, 1), fmap
 
 
-def bert_forward(sd, ids, attention_mask=None, token_type_ids=None, heads=12, eps=1e-12, prefix=""):
-    """HF BertModel.last_hidden_state (eval / dropout 0) from a state dict, fp32."""
+def bert_forward(sd, ids, attention_mask=None, token_type_ids=None, heads=12, eps=1e-12, prefix="", dropout=None):
+    """HF BertModel.last_hidden_state from a state dict, fp32.  dropout=None: eval mode.  dropout=(p_hidden, p_attention, seed):
+    training mode with the counter-based masks of oracle/dropout_oracle.py at HF's four dropout positions (BertEmbeddings after
+    its LayerNorm; BertSelfAttention on the probabilities; BertSelfOutput and BertOutput on the dense output before the residual
+    add) - the reference reaches them through model.train() (mmgclip/experiments/ClassifierExperiment.py:97)."""
     g = lambda k: sd[prefix + k]                                           # noqa: E731
     B, S = ids.shape
     if token_type_ids is None:
@@ -96,6 +99,17 @@ def bert_forward(sd, ids, attention_mask=None, token_type_ids=None, heads=12, ep
         + g("embeddings.position_embeddings.weight")[:S][None]
     H = x.shape[-1]
     x = F.layer_norm(x, (H,), g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
+    if dropout is not None:
+        from . import dropout_oracle as D
+        p_h, p_a, seed = dropout
+
+        def drop_hidden(t, site):
+            if p_h <= 0:
+                return t
+            keep = torch.from_numpy(D.hidden_mask(B * S, H, p_h, seed, site)).view(B, S, H)
+            return t * keep.to(t.dtype) * (1.0 / (1.0 - float(torch.tensor(p_h, dtype=torch.float32))))
+
+        x = drop_hidden(x, D.SITE_EMBEDDINGS)
     add = None
     if attention_mask is not None:
         add = (1.0 - attention_mask.to(x.dtype))[:, None, None, :] * torch.finfo(x.dtype).min
@@ -108,10 +122,18 @@ def bert_forward(sd, ids, attention_mask=None, token_type_ids=None, heads=12, ep
         s = q @ k.transpose(-1, -2) / (H // heads) ** 0.5
         if add is not None:
             s = s + add
-        ctx = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, S, H)
-        a = F.layer_norm(lin(ctx, "attention.output.dense") + x, (H,), g(p + "attention.output.LayerNorm.weight"),
-                         g(p + "attention.output.LayerNorm.bias"), eps)
+        prob = s.softmax(-1)
+        if dropout is not None and p_a > 0:
+            keep = torch.from_numpy(D.attention_mask(B, heads, S, p_a, seed, D.site_attention_probs(i)))
+            prob = prob * keep.to(prob.dtype) * (1.0 / (1.0 - float(torch.tensor(p_a, dtype=torch.float32))))
+        ctx = (prob @ v).permute(0, 2, 1, 3).reshape(B, S, H)
+        ao = lin(ctx, "attention.output.dense")
+        if dropout is not None:
+            ao = drop_hidden(ao, D.site_attention_output(i))
+        a = F.layer_norm(ao + x, (H,), g(p + "attention.output.LayerNorm.weight"), g(p + "attention.output.LayerNorm.bias"), eps)
         f = lin(F.gelu(lin(a, "intermediate.dense")), "output.dense")
+        if dropout is not None:
+            f = drop_hidden(f, D.site_ffn_output(i))
         x = F.layer_norm(f + a, (H,), g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"), eps)
         i += 1
     return x

@@ -13,6 +13,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "bert_dropout: the test exercises the text tower's training-mode dropout (default: off in tests)")
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_text_tower(request, monkeypatch):
+    """The parity tests compare training-mode towers with deterministic (eval-semantics) oracles, so the text tower's
+    training-mode dropout is switched off through its operational knob MMG_BERT_DROPOUT=0 (inherited by torchrun children).
+    Tests marked `bert_dropout` run with the product default (dropout live under train())."""
+    if request.node.get_closest_marker("bert_dropout") is None:
+        monkeypatch.setenv("MMG_BERT_DROPOUT", "0")
+    else:
+        monkeypatch.delenv("MMG_BERT_DROPOUT", raising=False)
 
 
 @pytest.fixture(scope="session")

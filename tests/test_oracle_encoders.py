@@ -26,6 +26,61 @@ def test_bert_restatement_matches_installed_transformers():
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
 
 
+def test_bert_training_mode_dropout_positions_match_installed_transformers(monkeypatch):
+    """The oracle's training-mode forward (counter-based masks, oracle/dropout_oracle.py) against HF BertModel in train() with
+    torch's dropout function replaced by one that applies the SAME masks in call order: pins WHERE dropout acts (embeddings after
+    LayerNorm, attention probabilities, the two dense outputs before their residual adds) to the third-party implementation the
+    reference calls (mmgclip/networks/encoder.py:156 under ClassifierExperiment.py:97)."""
+    transformers = pytest.importorskip("transformers")
+    from mmgclip.networks.bert import BertConfigLite, _hf_layout, hf_config_dict
+    from oracle import dropout_oracle as D
+    torch.manual_seed(0)
+    cfg = BertConfigLite(vocab_size=500, num_hidden_layers=2)
+    mine = _hf_layout(cfg)
+    hcfg = dict(hf_config_dict(cfg), hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    hf = transformers.BertModel(transformers.BertConfig(**hcfg, attn_implementation="eager"))
+    hf.load_state_dict(mine.state_dict(), strict=False)
+    hf.train()
+    B, S, H, heads, seed = 3, 20, cfg.hidden_size, 12, 2024
+    ids = torch.randint(1, 500, (B, S))
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, 12:] = 0
+    mask[2, 5:] = 0
+    calls = []
+
+    def masked_dropout(x, p=0.5, training=True, inplace=False):
+        n = len(calls)
+        calls.append(tuple(x.shape))
+        assert training and abs(p - 0.1) < 1e-9
+        if n == 0:
+            site = D.SITE_EMBEDDINGS
+        else:
+            layer, which = divmod(n - 1, 3)
+            site = (D.site_attention_probs, D.site_attention_output, D.site_ffn_output)[which](layer)
+        if x.dim() == 4:
+            assert x.shape == (B, heads, S, S)
+            keep = torch.from_numpy(D.attention_mask(B, heads, S, 0.1, seed, site))
+        else:
+            keep = torch.from_numpy(D.hidden_mask(B * S, H, 0.1, seed, site)).view(B, S, H)
+        return x * keep.to(x.dtype) * (1.0 / (1.0 - float(torch.tensor(0.1, dtype=torch.float32))))
+
+    monkeypatch.setattr(torch.nn.functional, "dropout", masked_dropout)
+    with torch.no_grad():
+        ref = hf(input_ids=ids, attention_mask=mask, token_type_ids=torch.zeros_like(ids))["last_hidden_state"]
+    monkeypatch.undo()
+    assert len(calls) == 1 + 3 * cfg.num_hidden_layers, calls
+    with torch.no_grad():
+        got = E.bert_forward(mine.state_dict(), ids, mask, None, heads=heads, dropout=(0.1, 0.1, seed))
+        plain = E.bert_forward(mine.state_dict(), ids, mask, None, heads=heads)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    assert float((got - plain).abs().max()) > 0.1            # the masks do act
+    # mask statistics and determinism of the generator itself
+    m = D.hidden_mask(4096, 768, 0.1, seed, 7)
+    assert abs(m.mean() - 0.9) < 2e-3 and (m == D.hidden_mask(4096, 768, 0.1, seed, 7)).all()
+    assert (m != D.hidden_mask(4096, 768, 0.1, seed, 8)).mean() > 0.1 and (m != D.hidden_mask(4096, 768, 0.1, seed + 1, 7)).mean() > 0.1
+    assert D.hidden_mask(64, 768, 0.0, seed, 1).all()
+
+
 def test_convnext_geometry_matches_notebook():
     """notebooks/clf_convnext_tiny_experimental.ipynb:641,682: [1,1,1906,818] -> features [1,768,59,25] -> avgpool [1,768,1,1]
     (checked on a proportionally smaller input to keep the CPU suite fast, plus the exact /32 floor rule)."""

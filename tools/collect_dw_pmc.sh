@@ -3,7 +3,7 @@ OUT=${1:-gpurun_out/dw_pmc}; REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." &
 mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" "SQ_INST_LEVEL_LDS SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU2 SQ_THREAD_CYCLES_VALU"; do
   rm -rf /tmp/pm$i
   rocprofv3 --pmc $set --output-format csv -d /tmp/pm$i -- python3 "$REPO/tools/dw_pmc.py" > "$OUT/pass$i.log" 2>&1 || true
   cp /tmp/pm$i/*/*counter_collection.csv "$OUT/pass$i.csv" 2>/dev/null || true

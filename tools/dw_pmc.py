@@ -9,3 +9,7 @@ out = torch.empty_like(x)
 for _ in range(3):
     K.dwconv7(x, w, b, n, H, H, C, out=out)
 torch.cuda.synchronize()
+dy = torch.randn_like(x); dw = torch.zeros(49, C, device=dev); db = torch.zeros(C, device=dev)
+for _ in range(3):
+    K.dwconv7_wgrad(x, dy, dw, db, n, H, H, C)
+torch.cuda.synchronize()
