@@ -4,9 +4,11 @@ CPU tests).  The reference has no multi-GPU path; this is the 
   exchange 1  all-gather of the L2-normalised image / text embeddings ([n_local, D] each)
   exchange 2  all-gather of the two log-sum-exp vectors (so embedding gradients are complete locally; no N x D
               reduce-scatter, no autograd through a collective)
-  exchange 3  SUM all-reduce of the parameter gradients: one flat buffer per tower arena + one coalesced buffer for
-              the small leftovers, issued on a side stream as soon as each tower's backward has finished so the
-              ConvNeXt all-reduce overlaps the BERT backward.
+  exchange 3  SUM all-reduce of the parameter gradients on a side stream, overlapped with the backward: a tower reports
+              finished layers / stages (`ParamArena.mark_ready`), contiguous ready ranges of its flat gradient buffer are
+              reduced in buckets of >= MMG_BUCKET_MB (default 32 MB: xGMI rings are per-link bound - few, large collectives)
+              while the earlier layers are still in backward; whatever is left goes when the tower's backward ends, plus one
+              coalesced buffer for the small leftovers (heads, logit_scale).
 The fused loss already carries the 1/(2N) factor of the GLOBAL mean, so gradients are summed, not averaged.
 """
 import os
@@ -62,36 +64,91 @@ def init_from_env(backend=None, single_rank=False):
     return Comm(always_exchange=single_rank and world <= 1)
 
 
-class GradSync:
-    """SUM all-reduce of parameter gradients, arena by arena, overlapped with the remaining backward work."""
+def _merge(ranges):
+    out = []
+    for lo, hi in sorted(ranges):
+        if out and lo <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], hi))
+        else:
+            out.append((lo, hi))
+    return out
 
-    def __init__(self, comm, arenas=(), extra_params=(), scale=1.0):
+
+def _complement(done, size):
+    out, at = [], 0
+    for lo, hi in _merge(done):
+        if lo > at:
+            out.append((at, lo))
+        at = max(at, hi)
+    if at < size:
+        out.append((at, size))
+    return out
+
+
+class GradSync:
+    """SUM all-reduce of parameter gradients, bucket by bucket, overlapped with the remaining backward work."""
+
+    def __init__(self, comm, arenas=(), extra_params=(), scale=1.0, bucket_bytes=None):
         self.comm = comm
         self.scale = float(scale)           # 1 for the global-batch loss (sum); 1/world for per-rank local losses (mean)
         self.arenas = [a for a in arenas if a is not None]
         self.extra = [p for p in extra_params]
         self.side = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.bucket_bytes = int(bucket_bytes if bucket_bytes is not None else float(os.environ.get("MMG_BUCKET_MB", "32")) * 2 ** 20)
         self._pending = []
+        self._state = {}                    # id(arena) -> {"done": ranges already reduced this step, "ready": ranges waiting for a bucket}
+        self.log = []                       # (id(arena), lo, hi) of every all-reduce of this step, in issue order (tests, diagnostics)
+        for a in self.arenas:               # towers call arena.mark_ready(...) as their backward retires layers
+            a.ready_hook = self.bucket_ready
 
-    def reduce_arena_async(self, arena):
-        """Call when this arena's backward has been enqueued on the current stream."""
-        if self.comm is None or not self.comm.active:
-            return
+    # ---- one collective --------------------------------------------------------------------------------------------
+    def _reduce_async(self, arena, lo, hi):
+        buf = arena.grad[lo:hi]
+        self.log.append((id(arena), lo, hi))
         if self.side is None:
-            self.comm.all_reduce_sum(arena.grad)
+            self.comm.all_reduce_sum(buf)
             if self.scale != 1.0:
-                arena.grad.mul_(self.scale)
+                buf.mul_(self.scale)
             return
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
-            self.comm.all_reduce_sum(arena.grad)
+            self.comm.all_reduce_sum(buf)
             if self.scale != 1.0:
-                arena.grad.mul_(self.scale)
+                buf.mul_(self.scale)
             done = torch.cuda.Event()
             done.record()
         self._pending.append(done)
+
+    def _st(self, arena):
+        return self._state.setdefault(id(arena), {"done": [], "ready": []})
+
+    def _flush(self, arena, st):
+        for lo, hi in _merge(st["ready"]):
+            self._reduce_async(arena, lo, hi)
+            st["done"].append((lo, hi))
+        st["ready"] = []
+
+    # ---- called by the towers -----------------------------------------------------------------------------------------
+    def bucket_ready(self, arena, lo, hi):
+        """Gradients [lo, hi) of this arena are final and their producers are enqueued on the current stream."""
+        if self.comm is None or not self.comm.active:
+            return
+        st = self._st(arena)
+        st["ready"].append((lo, hi))
+        if 4 * sum(b - a for a, b in st["ready"]) >= self.bucket_bytes:
+            self._flush(arena, st)
+
+    def reduce_arena_async(self, arena):
+        """Call when this arena's backward has been enqueued on the current stream: reduces everything not yet reduced."""
+        if self.comm is None or not self.comm.active:
+            return
+        st = self._st(arena)
+        st["ready"] = []
+        for lo, hi in _complement(st["done"], arena.size):
+            self._reduce_async(arena, lo, hi)
+        st["done"] = [(0, arena.size)]
 
     def finish(self):
         """Reduce the leftovers (projection heads, logit_scale) as ONE coalesced buffer and join the side stream."""
@@ -110,3 +167,5 @@ class GradSync:
         for ev in self._pending:
             torch.cuda.current_stream().wait_event(ev)
         self._pending.clear()
+        self._state.clear()
+        self.last_log, self.log = self.log, []

@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
-from ..params import ParamArena, backward_finished, note_forward
+from ..params import ParamArena, backward_finished, last_backward, note_forward
 
 
 class BertConfigLite:
@@ -279,7 +279,9 @@ class BertTower(nn.Module):
             x = full
         return x, saved
 
-    def _backward_mb(self, dx, saved):
+    def _backward_mb(self, dx, saved, final=False):
+        """final: last micro-batch of the step's last backward of this tower - a layer's gradients are complete once it has
+        passed, and are announced to the gradient all-reduce (ParamArena.mark_ready)."""
         cfg, wc, A = self.config, self._wc, self._arena
         B, S = saved["shape"]
         ids, tt, mask = saved["tok"]
@@ -324,6 +326,8 @@ class BertTower(nn.Module):
             dx = L.gemm_nt(dqkv, wc[f"{i}.wqkvt"], residual=da)       # + residual path of the attention block
             del dqkv, da
             saved["layers"][i] = None
+            if final:
+                A.mark_ready(p)
         emb, mean, rstd = saved["emb"]
         e = self.model.embeddings
         dx = masked(dx, self.SITE_EMBEDDINGS)
@@ -381,9 +385,9 @@ class _BertFn(torch.autograd.Function):
         tower._arena.prepare_grads()
         dh = dh.to(torch.bfloat16).contiguous()
         row = 0
-        for sv in ctx.saved_mb:
+        for k, sv in enumerate(ctx.saved_mb):
             B, S = sv["shape"]
-            tower._backward_mb(dh[row:row + B * S], sv)
+            tower._backward_mb(dh[row:row + B * S], sv, final=(k == len(ctx.saved_mb) - 1) and last_backward(tower))
             row += B * S
         ctx.saved_mb = None
         backward_finished(tower)

@@ -26,7 +26,7 @@ import torch.nn as nn
 from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
-from ..params import ParamArena, backward_finished, note_forward
+from ..params import ParamArena, backward_finished, last_backward, note_forward
 
 CONFIGS = {
     "tiny": dict(depths=(3, 3, 9, 3), dims=(96, 192, 384, 768)),
@@ -217,7 +217,11 @@ class ConvNextTower(nn.Module):
         saved["shape"] = (n, H, W)
         return feat, saved
 
-    def _backward_mb(self, dfeat, saved, tmp):
+    def _backward_mb(self, dfeat, saved, tmp, final=False, announce=False):
+        """final: last micro-batch of this backward - the GEMM-shaped temporaries of a stage are folded into the torch-layout
+        gradients as soon as the stage has passed; announce: it is also the tower's last backward of the step, so the stage's
+        gradients are complete and are handed to the gradient all-reduce (ParamArena.mark_ready) while the earlier, larger
+        feature maps are still in backward."""
         f, wc, A = self.model.features, self._wc, self._arena
         n, H, W = saved["shape"]
         h, w_ = H // 32, W // 32
@@ -269,9 +273,15 @@ class ConvNextTower(nn.Module):
                 K.dwconv7_wgrad(x, dd, tmp[key + ".dw49"], gname(blk.block[0], "bias"), n, h, w_, C)
                 dx = K.dwconv7(dd, wc[key + ".w49"], None, n, h, w_, C, add=dx, flip=True)
                 del dd
+            if final:
+                self._finalize_stage(tmp, si)
+                if announce:
+                    A.mark_ready((f"features.{1 + 2 * si}.",) + ((f"features.{2 + 2 * si}.",) if si < 3 else ()))
         p0, s0, mean, rstd = saved["stem"]
         ds0 = K.layernorm_bwd(dx, s0, mean, rstd, f[0][1].weight.data, gname(f[0][1], "weight"), gname(f[0][1], "bias"))
         L.gemm_tn_acc(ds0, p0, tmp["stem.dw"], colsum=gname(f[0][0], "bias"))
+        if final:
+            self._finalize_stem(tmp)
 
     def _alloc_tmp(self, device):
         z = lambda *s: torch.zeros(*s, device=device, dtype=torch.float32)   # noqa: E731
@@ -285,30 +295,36 @@ class ConvNextTower(nn.Module):
                 tmp[f"ds{si}.dw"] = z(self.dims[si + 1], 4 * C)
         return tmp
 
-    def _finalize_grads(self, tmp):
-        """Fold GEMM-shaped temporaries into the torch-layout gradients (layer scale, conv layouts)."""
+    def _finalize_stem(self, tmp):
+        """Fold the GEMM-shaped stem temporary into the torch-layout gradient."""
         f, A = self.model.features, self._arena
         from .._hip import call, ptr, stream
-        gname = lambda mod, leaf: A.g(self._pname[id(mod)] + "." + leaf)      # noqa: E731
         stem = f[0][0]
         # the stem temp is [C0, Kp] with zero-padded tail columns: relayout the first 16*Cin columns
         kk = 16 * self.in_chans
         src = tmp["stem.dw"][:, :kk].contiguous()
-        call("mmg_grad_relayout", ptr(src), ptr(gname(stem, "weight")), 0, self.dims[0], self.in_chans, 4, 4, kk, stream())
-        for si in range(4):
-            C = self.dims[si]
-            for bi, blk in enumerate(f[1 + 2 * si]):
-                key = f"{si}.{bi}"
-                call("mmg_layerscale_finalize", ptr(blk.block[5].weight.data), ptr(blk.block[5].bias.data),
-                     ptr(blk.layer_scale.data), ptr(tmp[key + ".dw2raw"]), ptr(tmp[key + ".db2raw"]),
-                     ptr(gname(blk.block[5], "weight")), ptr(gname(blk.block[5], "bias")),
-                     ptr(A.g(self._pname[id(blk)] + ".layer_scale")), C, 4 * C, stream())
-                call("mmg_grad_relayout", ptr(tmp[key + ".dw49"]), ptr(gname(blk.block[0], "weight")), 1, C, 1, 7, 7, C,
-                     stream())
-            if si < 3:
-                conv = f[2 + 2 * si][1]
-                call("mmg_grad_relayout", ptr(tmp[f"ds{si}.dw"]), ptr(gname(conv, "weight")), 0, self.dims[si + 1], C, 2, 2,
-                     4 * C, stream())
+        call("mmg_grad_relayout", ptr(src), ptr(A.g(self._pname[id(stem)] + ".weight")), 0, self.dims[0], self.in_chans, 4, 4, kk,
+             stream())
+
+    def _finalize_stage(self, tmp, si):
+        """Fold stage si's GEMM-shaped temporaries (and those of the downsample layer behind it) into the torch-layout gradients
+        (layer scale, conv layouts)."""
+        f, A = self.model.features, self._arena
+        from .._hip import call, ptr, stream
+        gname = lambda mod, leaf: A.g(self._pname[id(mod)] + "." + leaf)      # noqa: E731
+        C = self.dims[si]
+        for bi, blk in enumerate(f[1 + 2 * si]):
+            key = f"{si}.{bi}"
+            call("mmg_layerscale_finalize", ptr(blk.block[5].weight.data), ptr(blk.block[5].bias.data),
+                 ptr(blk.layer_scale.data), ptr(tmp[key + ".dw2raw"]), ptr(tmp[key + ".db2raw"]),
+                 ptr(gname(blk.block[5], "weight")), ptr(gname(blk.block[5], "bias")),
+                 ptr(A.g(self._pname[id(blk)] + ".layer_scale")), C, 4 * C, stream())
+            call("mmg_grad_relayout", ptr(tmp[key + ".dw49"]), ptr(gname(blk.block[0], "weight")), 1, C, 1, 7, 7, C,
+                 stream())
+        if si < 3:
+            conv = f[2 + 2 * si][1]
+            call("mmg_grad_relayout", ptr(tmp[f"ds{si}.dw"]), ptr(gname(conv, "weight")), 0, self.dims[si + 1], C, 2, 2,
+                 4 * C, stream())
 
     # ---- public -----------------------------------------------------------------------------------------------
     def feature_map_shape(self, H, W):
@@ -356,14 +372,14 @@ class _ConvNextFn(torch.autograd.Function):
         tmp = tower._alloc_tmp(dfeat.device)
         dfeat = dfeat.float().contiguous()
         i = 0
-        for sv in ctx.saved_mb:
+        for k, sv in enumerate(ctx.saved_mb):
             if "recompute" in sv:
                 _, sv = tower._forward_mb(sv["recompute"], True)
             n = sv["shape"][0]
-            tower._backward_mb(dfeat[i:i + n].contiguous(), sv, tmp)
+            final = k == len(ctx.saved_mb) - 1
+            tower._backward_mb(dfeat[i:i + n].contiguous(), sv, tmp, final=final, announce=final and last_backward(tower))
             sv.clear()
             i += n
-        tower._finalize_grads(tmp)
         ctx.saved_mb = None
         backward_finished(tower)
         return None, None, None

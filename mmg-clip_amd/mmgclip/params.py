@@ -34,6 +34,7 @@ class ParamArena:
             self._grad_views[n] = self.grad[o:o + p.numel()].view(p.shape)
         self._by_name = dict(named_params)
         self.manual_version = 0
+        self.ready_hook = None              # ready_hook(arena, lo, hi): gradients of elements [lo, hi) are final (distributed.GradSync)
 
     # ---- views -------------------------------------------------------------------------------------------
     def p(self, name):
@@ -89,6 +90,29 @@ class ParamArena:
     def any_trainable(self):
         return any(p.requires_grad for p in self.params)
 
+    # ---- "this part of the gradient is final" (bucketed all-reduce overlapped with the rest of the tower's backward) -------
+    def range_of(self, prefixes):
+        """[lo, hi) element range covering every parameter whose name starts with one of `prefixes` (they must be contiguous in
+        arena order, which holds for whole layers / stages); None when nothing matches."""
+        if isinstance(prefixes, str):
+            prefixes = (prefixes,)
+        idx = [i for i, n in enumerate(self.names) if n.startswith(tuple(prefixes))]
+        if not idx:
+            return None
+        assert idx == list(range(idx[0], idx[-1] + 1)), f"parameters under {prefixes} are not contiguous in the arena"
+        lo = self.offsets[self.names[idx[0]]]
+        hi = self.offsets[self.names[idx[-1] + 1]] if idx[-1] + 1 < len(self.names) else self.size
+        return lo, hi
+
+    def mark_ready(self, prefixes):
+        """Tower backward: every gradient under `prefixes` has received its last contribution of this step (the work that
+        produced it is enqueued on the current stream)."""
+        if self.ready_hook is None:
+            return
+        r = self.range_of(prefixes)
+        if r is not None:
+            self.ready_hook(self, r[0], r[1])
+
 
 # ---- when is a tower's gradient complete? ------------------------------------------------------------------------------------
 # A tower can run several times in one step (MMGCLIPLoss: the text tower encodes the report and the impression,
@@ -105,6 +129,11 @@ def backward_finished(tower):
     tower._open_backwards = max(0, getattr(tower, "_open_backwards", 0) - 1)
     if tower._open_backwards == 0 and tower.post_backward_hook is not None:
         tower.post_backward_hook(tower._arena)
+
+
+def last_backward(tower):
+    """True inside the LAST open backward of the tower for this step: only then are finished layers' gradients final."""
+    return getattr(tower, "_open_backwards", 1) <= 1
 
 
 def begin_step(tower):

@@ -203,6 +203,7 @@ def _train_worker(rank, world, port, tmp, loss_name, q):
 
 
 def _train_run(comm, rank, world, tmp, loss_name):
+    os.environ["MMG_BUCKET_MB"] = "8"          # several buckets per tower arena (ConvNeXt-T: 111 MB) in this small run
     full = _loader(steps=2, n=8, seed=31, with_impression=loss_name == "MMGCLIPLoss")
     exp = _experiment(tmp, ["optimizer.config.fused=true", "optimizer.config.learning_rate=1e-3", f"loss.config.loss_name={loss_name}"],
                       _HalfLoader(full, rank, world) if world > 1 else full, comm=comm)
@@ -210,7 +211,9 @@ def _train_run(comm, rank, world, tmp, loss_name):
     exp.scheduler.step()
     losses = [exp.train(), exp.train()]
     torch.cuda.synchronize()
-    return losses, {k: v.numpy() for k, v in _weights(exp).items()}, {k: v.numpy() for k, v in w0.items()}
+    sync = getattr(exp, "_sync", None)
+    ncoll = len(sync.last_log) if (sync is not None and world > 1) else 0      # all-reduces of the last step's tower gradients
+    return losses, {k: v.numpy() for k, v in _weights(exp).items()}, {k: v.numpy() for k, v in w0.items()}, ncoll
 
 
 @pytest.mark.parametrize("loss_name", ["CLIPLoss", "MMGCLIPLoss"])
@@ -229,11 +232,12 @@ def test_two_rank_experiment_train_equals_one_rank(dev, tmp_path, loss_name):
         p.join(timeout=120)
     assert all(r[1] == "ok" for r in results), [r[2] for r in results if r[1] != "ok"]
     assert all(p.exitcode == 0 for p in procs)
-    (l0, sd0, _), (l1, sd1, _) = results[0][2], results[1][2]
+    (l0, sd0, _, nc0), (l1, sd1, _, nc1) = results[0][2], results[1][2]
+    assert nc0 == nc1 and nc0 > 2, (nc0, nc1)                     # bucketed: more collectives than tower arenas, same on both ranks
     for k in sd0:
         assert np.array_equal(sd0[k], sd1[k]), k                  # the replicas are bit-identical after 4 optimizer steps
     assert np.allclose(l0, l1, rtol=1e-6)                         # global loss: the same number on both ranks
-    l_ref, ref, w0 = _train_run(None, 0, 1, str(tmp_path / "one"), loss_name)
+    l_ref, ref, w0, _ = _train_run(None, 0, 1, str(tmp_path / "one"), loss_name)
     assert np.allclose(l0, l_ref, rtol=5e-3), (l0, l_ref)         # bf16 towers see different micro-batches
     t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}    # noqa: E731
     cos, ratio = _delta_agreement(t(sd0), t(ref), t(w0))
