@@ -21,26 +21,50 @@
 #define DW_ROWD (DW_COLS * (DW_CB / 2) + 16)   // dwords per LDS row; +16 keeps rows r, r+1 on disjoint bank halves
 // DW_TH = 8 keeps the tile at 34 KiB so four workgroups share a CU (latency hiding for the LDS-read / FMA phases)
 
-// stage the halo tile of image n (tile origin h0,w0; channel slab c0) into LDS, zero outside the image.
+// Addressing.  The kernels are bound by VALU ISSUE (profiles/r02_dwconv_pmc.txt: 53 % of their VALU instructions were not FMAs), and
+// 64-bit pixel addresses cost quarter-rate v_mul_lo_u32 / v_mad_u64_u32 chains per load and store.  So: the image base
+// (n, channel slab) is uniform and stays in scalar registers; a lane adds a 32-BIT byte offset built from 24-bit multiplies
+// (v_mad_u32_u24, full rate) - the host checks H * W <= 2^24 pixels and H * W * C * 2 < 2^32 bytes per image.
+// a * b + c on the 24-bit multiplier (one full-rate instruction; hipcc turns __umul24(a, b) + c into the quarter-rate 64-bit
+// v_mad_u64_u32 when it cannot prove the operand ranges)
+__device__ __forceinline__ unsigned dw_mad24(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned dw_byte_off(int pix, int C, int chan) {          // ((pix * C) + chan) * 2
+    return dw_mad24((unsigned)pix, (unsigned)C, (unsigned)chan) << 1;
+}
+template <typename T>
+__device__ __forceinline__ const T* dw_at(const bf16_t* img, unsigned byte_off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(img) + byte_off);
+}
+
+// stage the halo tile (tile origin h0,w0) of the image / channel slab at `img` into LDS, zero outside the image.
 // All of a lane's 16-byte loads are issued before the first LDS store: one memory latency per tile instead of one per
-// chunk (the chunk-by-chunk loop made staging 3x longer than the 49-tap arithmetic).
+// chunk (the chunk-by-chunk loop made staging 3x longer than the 49-tap arithmetic).  Chunk it * 256 + tid is pixel
+// (it * 64 + tid / 4) of the 14 x 38 halo tile: walked as (row, col) += (1, 26) with a carry - no division.
 template <int ROWD = DW_ROWD>
-__device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ x, unsigned* tile, int n, int H, int W, int C, int h0,
-                                         int w0, int c0) {
+__device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ img, unsigned* tile, int H, int W, int C, int h0, int w0) {
     constexpr int CHUNKS = DW_ROWS * DW_COLS * (DW_CB / 8);
     constexpr int ITERS = (CHUNKS + 255) / 256;
+    static_assert(DW_CB == 32 && DW_COLS < 64 && 64 - DW_COLS < DW_COLS, "the (row, col) walk assumes 4 chunks per pixel, 38 columns");
     uint4 v[ITERS];
     int dst[ITERS];
+    const int ch = threadIdx.x & 3;
+    int col = threadIdx.x >> 2, row = 0;
+    if (col >= DW_COLS) { col -= DW_COLS; row = 1; }
+    const int pix00 = __mul24(h0 - 3, W) + (w0 - 3);                  // uniform; may be negative (then out of bounds below)
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int idx = it * 256 + threadIdx.x;
-        const int ch = idx & 3, pix = idx >> 2;
-        const int col = pix % DW_COLS, row = pix / DW_COLS;
         const int gh = h0 - 3 + row, gw = w0 - 3 + col;
         v[it] = make_uint4(0, 0, 0, 0);
-        dst[it] = idx < CHUNKS ? row * ROWD + col * (DW_CB / 2) + ch * 4 : -1;
-        if (idx < CHUNKS && gh >= 0 && gh < H && gw >= 0 && gw < W)
-            v[it] = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + gh) * W + gw) * C + c0 + ch * 8);
+        dst[it] = row < DW_ROWS ? row * ROWD + col * (DW_CB / 2) + ch * 4 : -1;
+        if (row < DW_ROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+            v[it] = *dw_at<uint4>(img, dw_byte_off((int)dw_mad24((unsigned)row, (unsigned)W, (unsigned)(pix00 + col)), C, ch * 8));
+        col += 64 - DW_COLS;
+        row += 1;
+        if (col >= DW_COLS) { col -= DW_COLS; row += 1; }
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it)
@@ -63,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restric
         const int k = i / DW_CB, c = i % DW_CB;
         ws[i] = w[(size_t)(FLIP ? 48 - k : k) * C + c0 + c];
     }
-    dw_stage(x, tile, n, H, W, C, h0, w0, c0);
+    dw_stage(x + (size_t)n * H * W * C + c0, tile, H, W, C, h0, w0);
     __syncthreads();
 
     const float b0 = bias ? bias[c0 + 2 * cp] : 0.f, b1 = bias ? bias[c0 + 2 * cp + 1] : 0.f;
@@ -148,18 +172,26 @@ __global__ __launch_bounds__(256, 2) void dwconv7_rows2_kernel(const bf16_t* __r
         const int k = i / DW_CB, c = i % DW_CB;
         ws[i] = w[(size_t)(FLIP ? 48 - k : k) * C + c0 + c];
     }
-    dw_stage<DW_ROWD2>(x, tile, n, H, W, C, h0, w0, c0);
+    const size_t slab = (size_t)n * H * W * C + c0;                 // uniform: this image, this channel slab
+    dw_stage<DW_ROWD2>(x + slab, tile, H, W, C, h0, w0);
     __syncthreads();
 
     const float b0 = bias ? bias[c0 + 2 * cp] : 0.f, b1 = bias ? bias[c0 + 2 * cp + 1] : 0.f;
     const int oh = 2 * r4;
+    // byte offsets of this lane's two output rows (pixel 0 of its strip); pixel p is p * C * 2 bytes further.  A tile that lies
+    // inside the image (uniform test) needs no per-pixel bounds checks.
+    const bool interior = h0 + DW_TH <= H && w0 + DW_TW <= W;
+    const unsigned pstep = (unsigned)C * 2u;
+    unsigned boff[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) boff[rr] = dw_byte_off((int)dw_mad24((unsigned)(h0 + oh + rr), (unsigned)W, (unsigned)(w0 + strip * 8)), C, 2 * cp);
     unsigned addv[2][8];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const int gh = h0 + oh + rr, gw = w0 + strip * 8 + p;
-            addv[rr][p] = (add && gh < H && gw < W) ? *reinterpret_cast<const unsigned*>(add + (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp) : 0u;
+            const bool in = interior || (h0 + oh + rr < H && w0 + strip * 8 + p < W);
+            addv[rr][p] = (add && in) ? *dw_at<unsigned>(add + slab, boff[rr] + p * pstep) : 0u;
         }
     float a0[2][8], a1[2][8];
 #pragma unroll
@@ -201,19 +233,16 @@ __global__ __launch_bounds__(256, 2) void dwconv7_rows2_kernel(const bf16_t* __r
             }
         }
     }
+    char* yslab = reinterpret_cast<char*>(y + slab);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        const int gh = h0 + oh + rr;
-        if (gh < H) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int gw = w0 + strip * 8 + p;
-                if (gw < W) {
-                    const size_t off = (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp;
-                    const unsigned o = pack2bf(a0[rr][p] + bf2f_lo(addv[rr][p]), a1[rr][p] + bf2f_hi(addv[rr][p]));
-                    if (nt) __builtin_nontemporal_store(o, reinterpret_cast<unsigned*>(y + off));
-                    else *reinterpret_cast<unsigned*>(y + off) = o;
-                }
+        for (int p = 0; p < 8; ++p) {
+            if (interior || (h0 + oh + rr < H && w0 + strip * 8 + p < W)) {
+                const unsigned o = pack2bf(a0[rr][p] + bf2f_lo(addv[rr][p]), a1[rr][p] + bf2f_hi(addv[rr][p]));
+                unsigned* dstp = reinterpret_cast<unsigned*>(yslab + (boff[rr] + p * pstep));
+                if (nt) __builtin_nontemporal_store(o, dstp);
+                else *dstp = o;
             }
         }
     }
@@ -242,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_kernel(const bf16_t* __r
         const int tw = tl % tiles_w, th = tl / tiles_w;
         const int h0 = th * DW_TH, w0 = tw * DW_TW;
         __syncthreads();
-        dw_stage(x, tile, n, H, W, C, h0, w0, c0);
+        dw_stage(x + (size_t)n * H * W * C + c0, tile, H, W, C, h0, w0);
         __syncthreads();
 #pragma unroll 1
         for (int pass = 0; pass < DW_TH / 4; ++pass) {
@@ -326,20 +355,24 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_rows2_kernel(const bf16_
         const int tw = tl % tiles_w, th = tl / tiles_w;
         const int h0 = th * DW_TH, w0 = tw * DW_TW;
         __syncthreads();
-        dw_stage<DW_ROWD2>(x, tile, n, H, W, C, h0, w0, c0);
+        const size_t slab = (size_t)n * H * W * C + c0;             // uniform: this image, this channel slab
+        dw_stage<DW_ROWD2>(x + slab, tile, H, W, C, h0, w0);
+        const bool interior = h0 + DW_TH <= H && w0 + DW_TW <= W;
+        const unsigned pstep = (unsigned)C * 2u;
         float g0[2][8], g1[2][8];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+        for (int rr = 0; rr < 2; ++rr) {
+            const unsigned boff = dw_byte_off((int)dw_mad24((unsigned)(h0 + oh + rr), (unsigned)W, (unsigned)(w0 + strip * 8)), C, 2 * cp);
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const int gh = h0 + oh + rr, gw = w0 + strip * 8 + p;
                 unsigned v = 0;
-                if (gh < H && gw < W) v = *reinterpret_cast<const unsigned*>(dy + (((size_t)n * H + gh) * W + gw) * C + c0 + 2 * cp);
+                if (interior || (h0 + oh + rr < H && w0 + strip * 8 + p < W)) v = *dw_at<unsigned>(dy + slab, boff + p * pstep);
                 g0[rr][p] = bf2f_lo(v);
                 g1[rr][p] = bf2f_hi(v);
                 sb0 += g0[rr][p];
                 sb1 += g1[rr][p];
             }
+        }
         __syncthreads();
         const unsigned* base = tile + oh * DW_ROWD2 + (strip * 8) * (DW_CB / 2) + cp;
 #pragma unroll
@@ -396,6 +429,9 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_rows2_kernel(const bf16_
 static int dw_check(const char* who, int n, int H, int W, int C) {
     MMG_CHECK_ARG(n > 0 && H > 0 && W > 0 && C > 0 && C % DW_CB == 0 && n <= 65535 && C / DW_CB <= 65535,
                   "%s: n=%d H=%d W=%d C=%d (C must be a multiple of 32)", who, n, H, W, C);
+    // 32-bit byte offsets inside one image, 24-bit pixel indices (dw_byte_off)
+    MMG_CHECK_ARG((long long)(H + 16) * (W + 64) <= (1LL << 24) && (long long)H * W * C * 2 < (1LL << 32),
+                  "%s: one image of %d x %d x %d exceeds the kernels' 32-bit addressing (H * W <= 2^24, H * W * C * 2 < 2^32)", who, H, W, C);
     return 0;
 }
 
