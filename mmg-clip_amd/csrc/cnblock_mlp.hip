@@ -34,6 +34,7 @@ struct MlpFwd {
     bf16_t* hpre;                           // optional [M,4C] pre-GELU hidden (for an unfused backward)
     float* mean; float* rstd;               // optional [M]
     long M; int ntiles;
+    int nt;                                 // 4C-wide output larger than the Infinity Cache: store it past L2 (nontemporal)
 };
 
 __device__ __forceinline__ void mlp_glds16(const void* gsrc, void* lds_wave_base) {
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
                     if (SAVE) {
                         const long row = row0 + 16 * mi;
                         if (row < p.M) {
-                            *reinterpret_cast<uint4*>(p.hpre + row * (4 * C) + n0) =
-                                make_uint4(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]), pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3]));
+                            store16_stream(p.hpre + row * (4 * C) + n0,
+                                           make_uint4(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]), pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3])), p.nt);
                         }
                     }
                     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -331,6 +332,7 @@ struct MlpBwd {
     const bf16_t* hpre;                     // [M,4C] saved pre-activation (RECOMP = false only)
     float* ln_dw; float* ln_db;             // optional [C]: fuse the LayerNorm backward (dxln then receives d loss / d xd)
     long M; int ntiles;
+    int nt;                                 // g / dh larger than the Infinity Cache: store them past L2 (nontemporal)
 };
 
 // sum over the 16 lanes of a DPP row (the lanes that share the same output columns); every lane gets the total
@@ -497,8 +499,8 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                     dhf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{dp[0], dp[1], dp[2], dp[3]}));
                     const long row = row0 + 16 * mi;
                     if (row < p.M) {
-                        *reinterpret_cast<uint4*>(p.g + row * (4 * C) + n0) = make_uint4(gp[0], gp[1], gp[2], gp[3]);
-                        *reinterpret_cast<uint4*>(p.dh + row * (4 * C) + n0) = make_uint4(dp[0], dp[1], dp[2], dp[3]);
+                        store16_stream(p.g + row * (4 * C) + n0, make_uint4(gp[0], gp[1], gp[2], gp[3]), p.nt);
+                        store16_stream(p.dh + row * (4 * C) + n0, make_uint4(dp[0], dp[1], dp[2], dp[3]), p.nt);
                     }
                 }
 #pragma unroll
@@ -594,9 +596,20 @@ static int mlp_cu_count() {
     return cus;
 }
 
+// The backward's 4C-wide outputs (g, dh) beyond the 256 MiB Infinity Cache are consumed much later by the weight-gradient GEMMs:
+// stored past L2 (nontemporal) from C = 128 up.  Same-run A/B (profiles/r02_mlp_nt_store_ab.txt): backward -8...-17 % at C = 192,
+// -12 % at 384, no change at 96; the forward's saved pre-activation is 1-3 % SLOWER that way and keeps plain stores.
+// MMG_MLP_NT_STORE=0/1 forces it off/on everywhere (read per call: A/B runs).
+static int mlp_nt_store(long M, int C, bool backward) {
+    const char* e = getenv("MMG_MLP_NT_STORE");
+    if (e) return atoi(e) != 0;
+    return backward && C >= 128 && (size_t)M * 4 * C * 2 >= ((size_t)256 << 20);
+}
+
 template <int C, bool RECOMP>
 static int launch_mlp_bwd(MlpBwd p, hipStream_t stream) {
     typedef MlpCfg<C> Cfg;
+    p.nt = mlp_nt_store(p.M, C, true);
     const size_t lds = 2 * ((RECOMP ? 3 : 2) * Cfg::NC * C * 2) + (size_t)8 * C * sizeof(float);
     p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     const int cap = Cfg::WGS_BWD * mlp_cu_count();
@@ -615,6 +628,7 @@ static int launch_mlp_bwd(MlpBwd p, hipStream_t stream) {
 template <int C>
 static int launch_mlp_fwd(MlpFwd p, hipStream_t stream) {
     typedef MlpCfg<C> Cfg;
+    p.nt = p.hpre ? mlp_nt_store(p.M, C, false) : 0;
     const size_t lds = 2 * (2 * Cfg::NC * C * 2) + (size_t)8 * C * sizeof(float);
     p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     const int cap = Cfg::WGS * mlp_cu_count();
@@ -672,7 +686,7 @@ MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* 
     MMG_CHECK_ARG((mean == nullptr) == (hpre == nullptr) && (rstd == nullptr) == (hpre == nullptr),
                   "mmg_cnblock_mlp_fwd: hpre, mean and rstd are saved together or not at all");
     MlpFwd p{(const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed, b1, b2, gamma, (const bf16_t*)residual, (bf16_t*)y,
-             (bf16_t*)hpre, mean, rstd, (long)M, 0};
+             (bf16_t*)hpre, mean, rstd, (long)M, 0, 0};
     switch (C) {
         case 96: return launch_mlp_fwd<96>(p, stream);
         case 128: return launch_mlp_fwd<128>(p, stream);
@@ -698,7 +712,7 @@ MMG_API int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_
     MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_bwd: bad M=%lld", M);
     MMG_CHECK_ARG((ln_dw == nullptr) == (ln_db == nullptr), "mmg_cnblock_mlp_bwd: ln_dw and ln_db go together");
     MlpBwd p{(const bf16_t*)dy, (const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed_bwd, b1, (bf16_t*)dh, (bf16_t*)g,
-             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (const bf16_t*)hpre, ln_dw, ln_db, (long)M, 0};
+             (bf16_t*)xln, (bf16_t*)dxln, mean, rstd, (const bf16_t*)hpre, ln_dw, ln_db, (long)M, 0, 0};
     switch (C) {
         case 96: return launch_mlp_bwd<96, true>(p, stream);
         case 128: return launch_mlp_bwd<128, true>(p, stream);
