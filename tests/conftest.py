@@ -38,3 +38,16 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def measured(name, **values):
+    """Append the values a tolerance test actually measured to gpurun_out/measured_tolerances.jsonl (the bars in the tests were
+    set from such a run; profiles/r02_measured_tolerances.jsonl is the committed copy)."""
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "measured_tolerances.jsonl"), "a") as fh:
+            fh.write(json.dumps({"test": name, **{k: (float(v) if not isinstance(v, (str, int)) else v) for k, v in values.items()}}) + "\n")
+    except OSError:
+        pass

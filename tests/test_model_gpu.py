@@ -8,6 +8,8 @@ import torch
 from oracle import clip_oracle as O
 from oracle import encoders_oracle as E
 
+from tests.conftest import measured
+
 pytestmark = pytest.mark.gpu
 CFG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmg-clip_amd", "configs")
 
@@ -61,10 +63,12 @@ def test_reference_faithful_mode(dev, monkeypatch):
     ref = _oracle_outputs(model, batch, pixels=False)
     out = model(batch)
     assert set(out) == {"image_embeddings", "text_embeddings", "logit_scale", "logits_per_image", "logits_per_text"}
-    np.testing.assert_allclose(out["logits_per_image"].detach().cpu().numpy(), ref["logits_per_image"].numpy(), atol=0.15)
+    np.testing.assert_allclose(out["logits_per_image"].detach().cpu().numpy(), ref["logits_per_image"].numpy(), atol=0.03)
     loss, labels = create_loss("CLIPLoss")()(**out)
     ref_loss, _ = O.clip_loss(ref["logits_per_image"], ref["logits_per_text"])
-    assert abs(loss.item() - ref_loss.item()) < 1e-2 * abs(ref_loss.item())      # bf16 towers vs fp32 oracle
+    measured("model_feature_mode_loss", loss_rel=abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()),
+             logits_abs_max=float((out["logits_per_image"].detach().cpu() - ref["logits_per_image"]).abs().max()))
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item())      # measured 7e-6 (frozen BERT, fp32 stream and head)
     assert labels.tolist() == list(range(32))
     loss.backward()
     assert model.image_projection_layer.layer.weight.grad is not None
@@ -92,7 +96,8 @@ def test_pixel_mode_training_step_matches_oracle_and_learns(dev, monkeypatch):
     out = model(batch, materialize_logits=False)
     assert "logits_per_image" not in out
     loss, _ = crit(**out)
-    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    measured("model_pixel_mode_loss", loss_rel=abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()))
+    assert abs(loss.item() - ref_loss.item()) < 1e-3 * abs(ref_loss.item()), (loss.item(), ref_loss.item())    # north-star bar; measured 1.6e-4
     loss.backward()
     opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-4,
                      arenas=[model.image_encoder.arena, model.text_encoder.arena])
@@ -206,7 +211,8 @@ def test_ragged_and_degenerate_batches(dev, monkeypatch, n, S):
     np.testing.assert_allclose(out["logits_per_image"].detach().cpu().numpy(), ref["logits_per_image"].numpy(), atol=0.25)
     loss, labels = create_loss("CLIPLoss")()(**out)
     ref_loss, _ = O.clip_loss(ref["logits_per_image"], ref["logits_per_text"])
-    assert abs(loss.item() - ref_loss.item()) < 2e-2 * max(abs(ref_loss.item()), 0.1)
+    measured("model_line209_loss", loss_rel=abs(loss.item() - ref_loss.item()) / max(abs(ref_loss.item()), 0.1))
+    assert abs(loss.item() - ref_loss.item()) < 2e-3 * max(abs(ref_loss.item()), 0.1)                       # measured <= 8.5e-4
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     fused, _ = create_loss("CLIPLoss")()(**model(batch, materialize_logits=False))

@@ -1,7 +1,9 @@
 """Encoder towers on the HIP kernels vs the fp32 CPU oracle (same state dict, same inputs).
 
-Tolerances: activations/weights are bf16 on the device (8 bits of mantissa), the oracle is fp32; features agree to
-~1e-2 relative, gradients are compared by cosine similarity (> 0.995) and relative L2 error (< 6e-2)."""
+Tolerances: activations/weights are bf16 on the device (8 bits of mantissa), the oracle is fp32.  The bars are ~1.5x what a run
+measures (profiles/r02_measured_tolerances.jsonl, written by tests.conftest.measured): ConvNeXt features 0.6-1.0e-2 relative
+(bar 1.5e-2), its parameter gradients <= 2.9e-2 / cosine >= 0.9996 (bars 4e-2 / 0.999); BERT hidden states 7e-3 (bar 1.5e-2),
+gradients <= 8.2e-2 / >= 0.9966 (bars 0.12 / 0.995: the worst ones are the near-zero key projections)."""
 import os
 
 import numpy as np
@@ -9,6 +11,7 @@ import pytest
 import torch
 
 from oracle import encoders_oracle as E
+from tests.conftest import measured
 
 pytestmark = pytest.mark.gpu
 
@@ -50,13 +53,16 @@ def test_convnext_tower_forward_backward(dev, size, n, variant):
     tower = tower.to(dev)
     feat = tower(img.to(dev))
     r, c = _rel(feat, pooled.flatten(1))
-    assert r < 2e-2 and c > 0.9995, (r, c)
+    fr, fc = r, c
+    assert r < 1.5e-2 and c > 0.9999, (r, c)
     (feat * wgt.to(dev)).sum().backward()
     worst = {}
     for name, p in tower.model.named_parameters():
         r, c = _rel(p.grad, osd[name].grad)
         worst[name] = (r, c)
-    bad = {k: v for k, v in worst.items() if not (v[1] > 0.995 and v[0] < 6e-2)}
+    measured("convnext_tower_forward_backward", variant=variant, size=size, n=n, feat_rel=fr, feat_cos=fc,
+             grad_rel_max=max(v[0] for v in worst.values()), grad_cos_min=min(v[1] for v in worst.values()))
+    bad = {k: v for k, v in worst.items() if not (v[1] > 0.999 and v[0] < 4e-2)}
     assert not bad, f"{len(bad)} of {len(worst)} gradients off: {list(bad.items())[:8]}"
 
 
@@ -98,11 +104,14 @@ def test_convnext_fp8_forward_matches_the_fp8_oracle(dev, variant, min_c):
     else:
         assert r8 < 0.1 and c8 > 0.995, (r8, c8)
     (feat * wgt.to(dev)).sum().backward()
-    bad = {}
+    bad, allg = {}, {}
     for name, p in tower.model.named_parameters():
         r, c = _rel(p.grad, osd[name].grad)
-        if not ((c > 0.99 and r < 0.15) if last_stage_only else (c > 0.95 and r < 0.35)):
+        allg[name] = (r, c)
+        if not ((c > 0.995 and r < 0.11) if last_stage_only else (c > 0.975 and r < 0.25)):      # measured 0.997 / 0.074 and 0.984 / 0.18
             bad[name] = (r, c)
+    measured("convnext_fp8_forward", variant=variant, min_c=min_c, feat_rel=r8, feat_cos=c8,
+             grad_rel_max=max(v[0] for v in allg.values()), grad_cos_min=min(v[1] for v in allg.values()))
     assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
 
 
@@ -131,9 +140,10 @@ def test_bert_tower_forward_backward(dev):
     enc = enc.to(dev)
     hid = enc.hidden_states({k: v.to(dev) for k, v in tok.items()})
     r, c = _rel(hid.float() * valid.to(dev), ref.reshape(-1, 768) * valid)
-    assert r < 3e-2 and c > 0.999, (r, c)
+    hr, hc = r, c
+    assert r < 1.5e-2 and c > 0.9999, (r, c)
     (hid.float() * (wgt * valid).to(dev)).sum().backward()
-    bad = {}
+    bad, allg = {}, {}
     for name, p in enc.model.named_parameters():
         if name.startswith("pooler."):
             continue
@@ -143,8 +153,11 @@ def test_bert_tower_forward_backward(dev):
             assert p.grad.abs().max() < 0.25 * qb.abs().max()
             continue
         r, c = _rel(p.grad, osd[name].grad)
-        if not (c > 0.99 and r < 0.12):
+        allg[name] = (r, c)
+        if not (c > 0.995 and r < 0.12):
             bad[name] = (r, c)
+    measured("bert_tower_forward_backward", hidden_rel=hr, hidden_cos=hc, grad_rel_max=max(v[0] for v in allg.values()),
+             grad_cos_min=min(v[1] for v in allg.values()), worst=max(allg, key=lambda k: allg[k][0]))
     assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
 
 
