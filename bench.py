@@ -269,6 +269,9 @@ def main():
                    "algorithmic_gflop_per_pair": gflop,
                    "model_tflops_per_gpu": round(value * gflop / 1000.0 / world, 1) if gflop else None,
                    "mfma_utilisation_model_flops": round(value * gflop / 1000.0 / world / MFMA_BF16_PEAK_TFLOPS, 4) if gflop else None,
+                   "text_dropout": ("HF training-mode dropout live (hidden 0.1, attention 0.1), as under the reference's model.train()"
+                                    if (model.text_encoder.training and getattr(model.text_encoder, "dropout", False)
+                                        and os.environ.get("MMG_BERT_DROPOUT", "1") != "0") else "off"),
                    "final_loss": round(losses[-1], 5),
                    "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
     }
