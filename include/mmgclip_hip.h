@@ -195,10 +195,11 @@ int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamm
 /* y = residual + gamma * ( GELU( LayerNorm(xd; ln_w, ln_b, eps) W1^T + b1 ) W2^T + b2 ), rows of [M,C] bf16.
  * Replaces CNBlock.block[2..5] + layer_scale + residual of torchvision ConvNeXt (mmgclip/networks/encoder.py:53) in one
  * launch: the 4C-wide hidden row stays in registers.  hpre (bf16 [M,4C], pre-GELU) and mean/rstd (fp32 [M]) are optional (all three or none)
- * outputs for a backward that does not recompute them. */
+ * outputs for a backward that does not recompute them; xln (bf16 [M,C], the LayerNorm output = operand of that backward's
+ * weight-gradient GEMM; optional, only next to hpre) saves it a LayerNorm pass.  (ABI 2: xln added.) */
 int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
                         const float* b1, const float* b2, const float* gamma, const void* residual, void* y, void* hpre,
-                        float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
+                        void* xln, float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
 
 /* Data path of the CNBlock MLP backward in one launch.  mmg_cnblock_mlp_bwd_supported(C): 1 (C in {96,128,192}) = the
  * hidden row h = LN(xd) W1^T + b1 is recomputed from the saved depthwise output, packed_bwd = pack(..., backward=1), hpre must

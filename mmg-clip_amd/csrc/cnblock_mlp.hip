@@ -32,6 +32,7 @@ struct MlpFwd {
     const bf16_t* res;                      // [M,C] block input
     bf16_t* y;                              // [M,C]
     bf16_t* hpre;                           // optional [M,4C] pre-GELU hidden (for an unfused backward)
+    bf16_t* xln;                            // optional [M,C] LayerNorm output (operand of that backward's weight-gradient GEMM)
     float* mean; float* rstd;               // optional [M]
     long M; int ntiles;
     int nt;                                 // 4C-wide output larger than the Infinity Cache: store it past L2 (nontemporal)
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
                                    fmaf((v[ks][2 * e + 1] - mean) * rstd, g[2 * e + 1], b[2 * e + 1]));
                 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
                 xf[mi][ks] = __builtin_bit_cast(bf16x8, (u32x4_t{o[0], o[1], o[2], o[3]}));
+                if (SAVE && p.xln && row < p.M) *reinterpret_cast<uint4*>(p.xln + row * C + 32 * ks + 8 * lg) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
 
@@ -679,14 +681,15 @@ MMG_API int mmg_cnblock_pack_weights(const float* w1, const float* w2, const flo
 
 MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
                                 const float* b1, const float* b2, const float* gamma, const void* residual, void* y,
-                                void* hpre, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
+                                void* hpre, void* xln, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
     MMG_CHECK_ARG(xd && ln_w && ln_b && packed && b1 && b2 && gamma && residual && y, "mmg_cnblock_mlp_fwd: null pointer");
     MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_mlp_fwd: C=%d not in {96,128,192,256,384,512}", C);
     MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_fwd: bad M=%lld", M);
     MMG_CHECK_ARG((mean == nullptr) == (hpre == nullptr) && (rstd == nullptr) == (hpre == nullptr),
                   "mmg_cnblock_mlp_fwd: hpre, mean and rstd are saved together or not at all");
+    MMG_CHECK_ARG(!xln || hpre, "mmg_cnblock_mlp_fwd: xln is saved next to hpre only");
     MlpFwd p{(const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed, b1, b2, gamma, (const bf16_t*)residual, (bf16_t*)y,
-             (bf16_t*)hpre, mean, rstd, (long)M, 0, 0};
+             (bf16_t*)hpre, (bf16_t*)xln, mean, rstd, (long)M, 0, 0};
     switch (C) {
         case 96: return launch_mlp_fwd<96>(p, stream);
         case 128: return launch_mlp_fwd<128>(p, stream);

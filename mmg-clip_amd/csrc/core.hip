@@ -11,7 +11,7 @@ void mmg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-MMG_API int mmg_abi_version(void) { return 1; }
+MMG_API int mmg_abi_version(void) { return 2; }
 MMG_API const char* mmg_last_error(void) { return g_err; }
 MMG_API const char* mmg_target_arch(void) { return "gfx950"; }
 

@@ -13,6 +13,7 @@ _PKG_ROOT = os.path.dirname(_HERE)                      # mmg-clip_amd/
 _REPO_ROOT = os.path.dirname(_PKG_ROOT)
 LIB_PATH = os.environ.get("MMGCLIP_HIP_LIB", os.path.join(_PKG_ROOT, "csrc", "libmmgclip_hip.so"))
 HEADER_PATH = os.path.join(_REPO_ROOT, "include", "mmgclip_hip.h")
+ABI_VERSION = 2      # 2: mmg_cnblock_mlp_fwd gained the optional xln output; the dropout entry points
 
 _CTYPES = {
     "int": ctypes.c_int,
@@ -83,8 +84,8 @@ def load():
                 raise HipLibraryError(f"{LIB_PATH} does not export {name} declared in {HEADER_PATH}") from e
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.mmg_abi_version() != 1:
-            raise HipLibraryError(f"ABI version mismatch: library reports {lib.mmg_abi_version()}, host expects 1")
+        if lib.mmg_abi_version() != ABI_VERSION:
+            raise HipLibraryError(f"ABI version mismatch: library reports {lib.mmg_abi_version()}, host expects {ABI_VERSION}")
         _lib = lib
     return _lib
 

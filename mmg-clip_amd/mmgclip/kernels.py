@@ -168,17 +168,19 @@ def cnblock_pack(w1, w2, gamma=None, backward=False):
     return out
 
 
-def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_hpre=False, want_stats=False):
+def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_hpre=False, want_stats=False, want_xln=False):
+    """-> y, hpre, mean, rstd (and, with want_xln, the LayerNorm output as a fifth value)."""
     M, C = xd.shape
     y = torch.empty_like(xd)
     hpre = torch.empty(M, 4 * C, device=xd.device, dtype=BF16) if want_hpre else None
+    xln = torch.empty(M, C, device=xd.device, dtype=BF16) if (want_xln and want_hpre) else None
     assert want_hpre == want_stats, "hpre and the LN statistics are saved together"
     mean = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
-    PROFILE.timed("cnblock_mlp_fwd_kernel", 16.0 * M * C * C, (6 + (8 if want_hpre else 0)) * M * C + 16 * C * C,
+    PROFILE.timed("cnblock_mlp_fwd_kernel", 16.0 * M * C * C, (6 + (8 if want_hpre else 0) + (2 if xln is not None else 0)) * M * C + 16 * C * C,
                   lambda: call("mmg_cnblock_mlp_fwd", ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed), ptr(b1), ptr(b2),
-                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(mean), ptr(rstd), M, C, stream()))
-    return y, hpre, mean, rstd
+                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(xln), ptr(mean), ptr(rstd), M, C, stream()))
+    return (y, hpre, mean, rstd, xln) if want_xln else (y, hpre, mean, rstd)
 
 
 def cnblock_bwd_mode(C):

@@ -91,6 +91,8 @@ class ConvNextTower(nn.Module):
         # narrow stages (C <= 256) run the CNBlock MLP as one fused launch; MMG_FUSED_MLP=0 keeps the GEMM pair
         self.fused_mlp = (os.environ.get("MMG_FUSED_MLP", "1") != "0") if fused_mlp is None else bool(fused_mlp)
         self.fused_bwd_saved_h = os.environ.get("MMG_FUSED_MLP_BWD_SAVED_H", "0") == "1"
+        # blocks whose backward is the GEMM pair keep their LayerNorm output ([M,C] bf16) instead of recomputing it (A/B: MMG_SAVE_LN=0)
+        self.save_ln = os.environ.get("MMG_SAVE_LN", "1") != "0"
         self.checkpoint = checkpoint        # recompute each micro-batch's forward in the backward (north-star config C5)
         # fp8 (config C5): the two pointwise GEMMs of every block with C % 128 == 0 and C >= fp8_min_channels run their FORWARD
         # on e4m3 operands (LayerNorm / GELU outputs cast unscaled, weights with a per-tensor power-of-two scale); the backward
@@ -182,11 +184,18 @@ class ConvNextTower(nn.Module):
                 # is saved for a backward - with the 4C-wide pre-activation store it is no faster than the GEMM pair)
                 if key + ".mlp" in wc and (C <= 384 or not save):
                     keep = save and key + ".mlpb" not in wc      # the fused backward recomputes the hidden row
-                    xn, hpre, mean, rstd = K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS,
-                                                             wc[key + ".mlp"], blk.block[3].bias.data, blk.block[5].bias.data,
-                                                             blk.layer_scale.data.reshape(C), x, want_hpre=keep, want_stats=keep)
+                    # a GEMM-pair backward (C = 384 by default) also gets the LayerNorm output from the forward's registers: one
+                    # [M,C] store instead of a LayerNorm pass over d in the backward
+                    keep_ln = keep and self.save_ln and key + ".mlpb2" not in wc
+                    xn, hpre, mean, rstd, ln = K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS,
+                                                                 wc[key + ".mlp"], blk.block[3].bias.data, blk.block[5].bias.data,
+                                                                 blk.layer_scale.data.reshape(C), x, want_hpre=keep, want_stats=keep,
+                                                                 want_xln=True)[:5] if keep_ln else \
+                        K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, wc[key + ".mlp"],
+                                          blk.block[3].bias.data, blk.block[5].bias.data, blk.layer_scale.data.reshape(C), x,
+                                          want_hpre=keep, want_stats=keep) + (None,)
                     if save:
-                        saved[key] = (x, d, mean, rstd, hpre)
+                        saved[key] = (x, d, mean, rstd, hpre, ln)
                     x = xn
                     continue
                 hpre = torch.empty(x.shape[0], 4 * C, device=x.device, dtype=torch.bfloat16) if save else None
@@ -201,8 +210,8 @@ class ConvNextTower(nn.Module):
                     g = L.gemm_nt(ln, wc[key + ".w1"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre)
                     xn = L.gemm_nt(g, wc[key + ".w2"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
                                    residual=x)
-                if save:
-                    saved[key] = (x, d, mean, rstd, hpre)
+                if save:                         # (an e4m3 LayerNorm output is not what the bf16 backward reads: that one is recomputed)
+                    saved[key] = (x, d, mean, rstd, hpre, ln if (self.save_ln and ln.dtype == torch.bfloat16) else None)
                 del ln, g
                 x = xn
             if si < 3:
@@ -241,7 +250,7 @@ class ConvNextTower(nn.Module):
             for bi in range(self.depths[si] - 1, -1, -1):
                 blk = f[1 + 2 * si][bi]
                 key = f"{si}.{bi}"
-                x, d, mean, rstd, hpre = saved[key]
+                x, d, mean, rstd, hpre, ln_saved = saved[key]
                 if hpre is None or key + ".mlpb2" in wc:   # fused data path (hidden row recomputed on chip / read back)
                     # C <= 128: the LayerNorm backward rides in the epilogue (`dd` comes back instead of d LN-out); wider
                     # blocks have no registers left for it
@@ -261,7 +270,8 @@ class ConvNextTower(nn.Module):
                     dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
                     L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
                     del g
-                    ln, _, _ = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=False)
+                    ln = ln_saved if ln_saved is not None else \
+                        K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=False)[0]
                     L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
                     del ln
                     dln = L.gemm_nt(dh, wc[key + ".w1t"])

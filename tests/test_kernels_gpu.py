@@ -273,6 +273,12 @@ def test_fused_cnblock_mlp_forward_matches_unfused_reference(dev, C, M):
     assert torch.allclose(rstd.cpu(), (xd.float().var(1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-4)
     y2, _, _, _ = K.cnblock_mlp_fwd(d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1), d(b2), d(gamma), d(res))
     assert torch.equal(y2, y)
+    # optional LayerNorm output next to hpre (what a GEMM-pair backward reads instead of recomputing it): the unfused kernel's bits
+    y3, hpre3, _, _, xln = K.cnblock_mlp_fwd(d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1), d(b2), d(gamma), d(res),
+                                             want_hpre=True, want_stats=True, want_xln=True)
+    ln_dev, _, _ = K.layernorm_fwd(d(xd), d(lnw), d(lnb), 1e-6, want_stats=False)
+    assert torch.equal(y3, y) and torch.equal(hpre3, hpre)
+    assert torch.allclose(xln.float(), ln_dev.float(), atol=2e-2, rtol=1e-2) and (xln != ln_dev).float().mean() < 0.02
 
 
 @pytest.mark.parametrize("C,M", [(96, 128 * 3 + 50), (128, 200), (192, 333), (384, 128 + 77)])
