@@ -44,9 +44,9 @@ __device__ __forceinline__ const T* dw_at(const bf16_t* img, unsigned byte_off) 
 // All of a lane's 16-byte loads are issued before the first LDS store: one memory latency per tile instead of one per
 // chunk (the chunk-by-chunk loop made staging 3x longer than the 49-tap arithmetic).  Chunk it * 256 + tid is pixel
 // (it * 64 + tid / 4) of the 14 x 38 halo tile: walked as (row, col) += (1, 26) with a carry - no division.
-template <int ROWD = DW_ROWD>
+template <int ROWD = DW_ROWD, int ROWS = DW_ROWS>
 __device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ img, unsigned* tile, int H, int W, int C, int h0, int w0) {
-    constexpr int CHUNKS = DW_ROWS * DW_COLS * (DW_CB / 8);
+    constexpr int CHUNKS = ROWS * DW_COLS * (DW_CB / 8);
     constexpr int ITERS = (CHUNKS + 255) / 256;
     static_assert(DW_CB == 32 && DW_COLS < 64 && 64 - DW_COLS < DW_COLS, "the (row, col) walk assumes 4 chunks per pixel, 38 columns");
     uint4 v[ITERS];
@@ -59,8 +59,8 @@ __device__ __forceinline__ void dw_stage(const bf16_t* __restrict__ img, unsigne
     for (int it = 0; it < ITERS; ++it) {
         const int gh = h0 - 3 + row, gw = w0 - 3 + col;
         v[it] = make_uint4(0, 0, 0, 0);
-        dst[it] = row < DW_ROWS ? row * ROWD + col * (DW_CB / 2) + ch * 4 : -1;
-        if (row < DW_ROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+        dst[it] = row < ROWS ? row * ROWD + col * (DW_CB / 2) + ch * 4 : -1;
+        if (row < ROWS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
             v[it] = *dw_at<uint4>(img, dw_byte_off((int)dw_mad24((unsigned)row, (unsigned)W, (unsigned)(pix00 + col)), C, ch * 8));
         col += 64 - DW_COLS;
         row += 1;
@@ -335,15 +335,18 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_kernel(const bf16_t* __r
 
 // Weight gradient with two dy rows per lane (same idea as dwconv7_rows2_kernel: the 8 input rows under a row pair are read
 // and unpacked once for both).  Input row r meets dy row 0 at kernel row r and dy row 1 at kernel row r-1.
+// TH = tile height: 8, or 16 in two passes over the staged tile - the halo then costs (16+6)(32+6) / (16*32) = 1.63 x the tile
+// instead of 2.08 x (PMC, round 1: 5.39 GB fetched per launch against 2.55 GB algorithmic = exactly that ratio).
+template <int TH>
 __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_rows2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                      float* __restrict__ dw, float* __restrict__ dbias, int N,
                                                                      int H, int W, int C, int tiles_w, int tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
     unsigned* tile = smem_u;
-    float* red = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD2);    // [4 waves][50][32]
+    constexpr int ROWS = TH + 6;
+    float* red = reinterpret_cast<float*>(smem_u + ROWS * DW_ROWD2);    // [4 waves][50][32]
     const int c0 = blockIdx.y * DW_CB;
     const int cp = threadIdx.x & 15, r4 = (threadIdx.x >> 4) & 3, strip = threadIdx.x >> 6;
-    const int oh = 2 * r4;
 
     float d0[49], d1[49];
 #pragma unroll
@@ -353,12 +356,15 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_rows2_kernel(const bf16_
     for (int item = blockIdx.x; item < N * tiles; item += gridDim.x) {
         const int n = item / tiles, tl = item - n * tiles;
         const int tw = tl % tiles_w, th = tl / tiles_w;
-        const int h0 = th * DW_TH, w0 = tw * DW_TW;
+        const int h0 = th * TH, w0 = tw * DW_TW;
         __syncthreads();
         const size_t slab = (size_t)n * H * W * C + c0;             // uniform: this image, this channel slab
-        dw_stage<DW_ROWD2>(x + slab, tile, H, W, C, h0, w0);
-        const bool interior = h0 + DW_TH <= H && w0 + DW_TW <= W;
+        dw_stage<DW_ROWD2, ROWS>(x + slab, tile, H, W, C, h0, w0);
+        const bool interior = h0 + TH <= H && w0 + DW_TW <= W;
         const unsigned pstep = (unsigned)C * 2u;
+#pragma unroll 1
+        for (int pass = 0; pass < TH / 8; ++pass) {
+        const int oh = 8 * pass + 2 * r4;
         float g0[2][8], g1[2][8];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_rows2_kernel(const bf16_
                 sb1 += g1[rr][p];
             }
         }
-        __syncthreads();
+        if (pass == 0) __syncthreads();                              // the staged tile is complete (uniform branch)
         const unsigned* base = tile + oh * DW_ROWD2 + (strip * 8) * (DW_CB / 2) + cp;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(256, 1) void dwconv7_wgrad_rows2_kernel(const bf16_
                         d1[(r - 1) * 7 + kw] = fmaf(i1[p + kw], g1[1][p], d1[(r - 1) * 7 + kw]);
                     }
             }
+        }
         }
     }
     __syncthreads();
@@ -489,7 +496,11 @@ MMG_API int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* d
                               hipStream_t stream) {
     if (dw_check("mmg_dwconv7_wgrad", n, H, W, C)) return 1;
     MMG_CHECK_ARG(x && dy && dw, "mmg_dwconv7_wgrad: null pointer");
-    const int tiles_w = cdiv(W, DW_TW), tiles_h = cdiv(H, DW_TH);
+    const int rows2 = getenv("MMG_DWCONV_ROWS2") ? atoi(getenv("MMG_DWCONV_ROWS2")) : 1;
+    // tile height of the two-rows-per-lane kernel: 16 where the map is tall enough to fill the persistent grid (halo 1.63x), else 8
+    const int th_env = getenv("MMG_DWG_TH") ? atoi(getenv("MMG_DWG_TH")) : 0;
+    const int TH = rows2 ? (th_env == 8 || th_env == 16 ? th_env : ((long)n * cdiv(H, 16) * cdiv(W, DW_TW) * (C / DW_CB) >= 2048 ? 16 : 8)) : DW_TH;
+    const int tiles_w = cdiv(W, DW_TW), tiles_h = cdiv(H, TH);
     const size_t shm = (size_t)DW_ROWS * DW_ROWD * 4 + 4 * 50 * DW_CB * 4;
     // ~1024 workgroups in total (4 per CU), each walking its share of the (image, tile) items of one channel slab
     const int tiles = tiles_w * tiles_h, slabs = C / DW_CB;
@@ -501,12 +512,17 @@ MMG_API int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* d
     if (align8 && per_slab >= 8) per_slab &= ~7;
     if (per_slab < 1) per_slab = 1;
     if (per_slab > n * tiles) per_slab = n * tiles;
-    const int rows2 = getenv("MMG_DWCONV_ROWS2") ? atoi(getenv("MMG_DWCONV_ROWS2")) : 1;
     if (rows2) {
-        const size_t shm2 = (size_t)DW_ROWS * DW_ROWD2 * 4 + 4 * 50 * DW_CB * 4;
-        mmg_allow_lds(dwconv7_wgrad_rows2_kernel, shm2);
-        hipLaunchKernelGGL(dwconv7_wgrad_rows2_kernel, dim3(per_slab, slabs), dim3(256), shm2, stream, (const bf16_t*)x,
-                           (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w, tiles);
+        const size_t shm2 = (size_t)(TH + 6) * DW_ROWD2 * 4 + 4 * 50 * DW_CB * 4;
+        if (TH == 16) {
+            mmg_allow_lds(dwconv7_wgrad_rows2_kernel<16>, shm2);
+            hipLaunchKernelGGL(dwconv7_wgrad_rows2_kernel<16>, dim3(per_slab, slabs), dim3(256), shm2, stream, (const bf16_t*)x,
+                               (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w, tiles);
+        } else {
+            mmg_allow_lds(dwconv7_wgrad_rows2_kernel<8>, shm2);
+            hipLaunchKernelGGL(dwconv7_wgrad_rows2_kernel<8>, dim3(per_slab, slabs), dim3(256), shm2, stream, (const bf16_t*)x,
+                               (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w, tiles);
+        }
         MMG_LAUNCH_CHECK("mmg_dwconv7_wgrad");
         return 0;
     }

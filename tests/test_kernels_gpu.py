@@ -137,8 +137,9 @@ def test_dwconv7(dev, n, H, W, C, monkeypatch):
     _close(y2.reshape(n, H, W, C), ref.permute(0, 2, 3, 1), 1e-2, 3e-2)
     dx2 = K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True, mfma=True)
     _close(dx2.reshape(n, H, W, C), xr.grad.permute(0, 2, 3, 1) + res.float().reshape(n, H, W, C), 1e-2, 4e-2)
-    for rows2 in ("1", "0"):                      # two dy rows per lane (default) / one
+    for rows2, th in (("1", "8"), ("1", "16"), ("0", "8")):   # two dy rows per lane on 8- and 16-row tiles (defaults by size) / one
         monkeypatch.setenv("MMG_DWCONV_ROWS2", rows2)
+        monkeypatch.setenv("MMG_DWG_TH", th)
         dw, db = torch.zeros(49, C, device=dev), torch.zeros(C, device=dev)
         K.dwconv7_wgrad(x.reshape(-1, C), dy.reshape(-1, C), dw, db, n, H, W, C)
         _close(dw, wr.grad.reshape(C, 49).t(), 2e-3, 2e-3 * (n * H * W) ** 0.5)
