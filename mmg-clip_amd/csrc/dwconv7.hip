@@ -156,16 +156,20 @@ __global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restric
 // (kh, kw) order as above: bit-identical results.  The row pitch is 616 dwords so that the four row groups of a wave, now
 // two rows apart, still start 16 banks apart.
 #define DW_ROWD2 (DW_COLS * (DW_CB / 2) + 8)
-template <bool FLIP>
+#define DW_FWD_TH_DEFAULT 8
+// TH = tile height: 8 (four workgroups per CU) or 16 (two passes over one staged 22-row tile, two workgroups per CU: halo 1.21x
+// instead of 1.4x, staging and tap loads amortised over twice the pixels).
+template <bool FLIP, int TH>
 __global__ __launch_bounds__(256, 2) void dwconv7_rows2_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, const bf16_t* __restrict__ add,
                                                                bf16_t* __restrict__ y, int H, int W, int C, int tiles_w, int nt) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
-    unsigned* tile = smem_u;                                              // [DW_ROWS][DW_ROWD2] dwords (bf16 pairs)
-    float* ws = reinterpret_cast<float*>(smem_u + DW_ROWS * DW_ROWD2);    // [49][32]
+    constexpr int ROWS = TH + 6;
+    unsigned* tile = smem_u;                                              // [ROWS][DW_ROWD2] dwords (bf16 pairs)
+    float* ws = reinterpret_cast<float*>(smem_u + ROWS * DW_ROWD2);       // [49][32]
     const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
     const int c0 = blockIdx.y * DW_CB, n = blockIdx.z;
-    const int h0 = th * DW_TH, w0 = tw * DW_TW;
+    const int h0 = th * TH, w0 = tw * DW_TW;
     const int cp = threadIdx.x & 15, r4 = (threadIdx.x >> 4) & 3, strip = threadIdx.x >> 6;
 
     for (int i = threadIdx.x; i < 49 * DW_CB; i += 256) {
@@ -173,14 +177,17 @@ __global__ __launch_bounds__(256, 2) void dwconv7_rows2_kernel(const bf16_t* __r
         ws[i] = w[(size_t)(FLIP ? 48 - k : k) * C + c0 + c];
     }
     const size_t slab = (size_t)n * H * W * C + c0;                 // uniform: this image, this channel slab
-    dw_stage<DW_ROWD2>(x + slab, tile, H, W, C, h0, w0);
+    dw_stage<DW_ROWD2, ROWS>(x + slab, tile, H, W, C, h0, w0);
     __syncthreads();
 
     const float b0 = bias ? bias[c0 + 2 * cp] : 0.f, b1 = bias ? bias[c0 + 2 * cp + 1] : 0.f;
-    const int oh = 2 * r4;
+    char* yslab = reinterpret_cast<char*>(y + slab);
+#pragma unroll 1
+    for (int pass = 0; pass < TH / 8; ++pass) {
+    const int oh = 8 * pass + 2 * r4;
     // byte offsets of this lane's two output rows (pixel 0 of its strip); pixel p is p * C * 2 bytes further.  A tile that lies
     // inside the image (uniform test) needs no per-pixel bounds checks.
-    const bool interior = h0 + DW_TH <= H && w0 + DW_TW <= W;
+    const bool interior = h0 + TH <= H && w0 + DW_TW <= W;
     const unsigned pstep = (unsigned)C * 2u;
     unsigned boff[2];
 #pragma unroll
@@ -233,7 +240,6 @@ __global__ __launch_bounds__(256, 2) void dwconv7_rows2_kernel(const bf16_t* __r
             }
         }
     }
-    char* yslab = reinterpret_cast<char*>(y + slab);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
 #pragma unroll
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_rows2_kernel(const bf16_t* __r
                 else *dstp = o;
             }
         }
+    }
     }
 }
 
@@ -465,16 +472,20 @@ MMG_API int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, c
     const int nt = (size_t)n * H * W * C * 2 >= ((size_t)256 << 20);
     const int rows2 = getenv("MMG_DWCONV_ROWS2") ? atoi(getenv("MMG_DWCONV_ROWS2")) : 1;      // read per call (tests / A-B runs)
     if (rows2) {
-        const size_t shm2 = (size_t)DW_ROWS * DW_ROWD2 * 4 + 49 * DW_CB * 4;
-        if (flip) {
-            mmg_allow_lds(dwconv7_rows2_kernel<true>, shm2);
-            hipLaunchKernelGGL(dwconv7_rows2_kernel<true>, grid, dim3(256), shm2, stream, (const bf16_t*)x, w, bias,
-                               (const bf16_t*)add, (bf16_t*)y, H, W, C, tiles_w, nt);
-        } else {
-            mmg_allow_lds(dwconv7_rows2_kernel<false>, shm2);
-            hipLaunchKernelGGL(dwconv7_rows2_kernel<false>, grid, dim3(256), shm2, stream, (const bf16_t*)x, w, bias,
-                               (const bf16_t*)add, (bf16_t*)y, H, W, C, tiles_w, nt);
-        }
+        // 16-row tiles from MMG_DWCONV_TH=16 (A/B knob; default 8)
+        const int th16 = getenv("MMG_DWCONV_TH") ? atoi(getenv("MMG_DWCONV_TH")) == 16 : DW_FWD_TH_DEFAULT == 16;
+        const int TH = th16 ? 16 : 8;
+        const size_t shm2 = (size_t)(TH + 6) * DW_ROWD2 * 4 + 49 * DW_CB * 4;
+        const dim3 grid2(tiles_w * cdiv(H, TH), C / DW_CB, n);
+#define DW_LAUNCH2(FL, T)                                                                                          \
+        do {                                                                                                       \
+            mmg_allow_lds(dwconv7_rows2_kernel<FL, T>, shm2);                                                      \
+            hipLaunchKernelGGL((dwconv7_rows2_kernel<FL, T>), grid2, dim3(256), shm2, stream, (const bf16_t*)x, w, bias, \
+                               (const bf16_t*)add, (bf16_t*)y, H, W, C, tiles_w, nt);                              \
+        } while (0)
+        if (flip) { if (th16) DW_LAUNCH2(true, 16); else DW_LAUNCH2(true, 8); }
+        else      { if (th16) DW_LAUNCH2(false, 16); else DW_LAUNCH2(false, 8); }
+#undef DW_LAUNCH2
         MMG_LAUNCH_CHECK("mmg_dwconv7_nhwc");
         return 0;
     }

@@ -132,6 +132,10 @@ def test_dwconv7(dev, n, H, W, C, monkeypatch):
     assert torch.equal(K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C), y)
     assert torch.equal(K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True), dx)
     monkeypatch.undo()
+    monkeypatch.setenv("MMG_DWCONV_TH", "16")     # 16-row tiles (two passes over one staged tile): the same sums in the same order
+    assert torch.equal(K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C), y)
+    assert torch.equal(K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True), dx)
+    monkeypatch.undo()
     # the matrix-core formulation of the same two launches (Toeplitz-operand MFMAs, taps in bf16)
     y2 = K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C, mfma=True)
     _close(y2.reshape(n, H, W, C), ref.permute(0, 2, 3, 1), 1e-2, 3e-2)
