@@ -423,8 +423,11 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     const bool n96 = (N % 128 != 0) && (N % 96 == 0);
     // K < 384 (ConvNeXt stages 1-2, stem): HBM/latency bound -> 16 KiB stages, three of them, three workgroups per CU
     static const int use_3wg = getenv("MMG_GEMM_3WG") ? atoi(getenv("MMG_GEMM_3WG")) : 1;
-    static const int k3_max = getenv("MMG_GEMM_K3") ? atoi(getenv("MMG_GEMM_K3")) : 384;       // 3-WG config below this K
-    static const int kbig_min = getenv("MMG_GEMM_KBIG") ? atoi(getenv("MMG_GEMM_KBIG")) : 512;  // 256x128 config from this K
+    // (round 2, tools/nt_knobs.py, profiles/r02_nt_tile_rules.txt: the 4.2 M x 384 x 192 data gradient of the first downsample layer ran
+    // 30 % faster on the two-stage 128 x 128 x 64 tile than on the three-workgroup one, the N = 384 long-K shapes 2-4 % faster on it than
+    // on 256 x 128; BERT's shapes do not care)
+    static const int k3_max = getenv("MMG_GEMM_K3") ? atoi(getenv("MMG_GEMM_K3")) : 128;       // 3-WG config below this K
+    static const int kbig_min = getenv("MMG_GEMM_KBIG") ? atoi(getenv("MMG_GEMM_KBIG")) : 4096; // 256x128 config from this K
     // 256x256 tile (8 waves, one workgroup per CU): 128 FLOP per operand byte pulled from L2, which is what bounds the
     // 128-wide tiles (~10 TB/s of L2->LDS traffic); used from this K upwards when N is a multiple of 256 (0 = never)
     static const int use_256 = getenv("MMG_GEMM_256") ? atoi(getenv("MMG_GEMM_256")) : 384;
