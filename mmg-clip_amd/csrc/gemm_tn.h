@@ -11,6 +11,9 @@ struct GemmTN {
     int tiles1, tiles2, rows_per_chunk;
     float alpha;
     int chunks, xcd_order;    // xcd_order: 0 = (tile, chunk) grid, 1 / 2 = XCD-grouped by the B / A block (see the kernels)
+    // wide-tile kernel only: the caller's operands were exchanged (its A is this B) so that the wide side is N2; the tile is flushed
+    // TRANSPOSED (C points at the caller's [N2, N1] matrix, ldc its leading dimension) and `colsum_a` holds sums of B's columns
+    int swapped;
 };
 
 // Launches the wide-tile kernel when the shape suits it; returns false (nothing launched) otherwise.

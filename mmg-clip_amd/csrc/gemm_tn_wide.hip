@@ -193,10 +193,15 @@ __global__ __launch_bounds__(TW_THREADS, 2) void gemm_tn_wide_kernel(const GemmT
     // bias gradient = column sums of A, in the first tile column only: the lane adds up its own 8 reduction rows of each A
     // fragment with v_dot2c_f32_bf16 against (1, 1) - one register per fragment (an MFMA against an all-ones operand would keep
     // four), the VALU is idle in this kernel; the 4 lane groups of a column are summed at the end
-    const bool do_colsum = (g.colsum_a != nullptr) && (t2 == 0) && (w2 == 0);
+    const bool do_colsum = (g.colsum_a != nullptr) && !g.swapped && (t2 == 0) && (w2 == 0);
     float csum[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) csum[i] = 0.f;
+    // exchanged operands (g.swapped): the caller's A is this kernel's B - the same sums over the B fragments, first tile ROW only
+    const bool do_colsum_b = (g.colsum_a != nullptr) && g.swapped && (t1 == 0) && (w1 == 0);
+    float csum_b[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) csum_b[j] = 0.f;
 
 #pragma unroll
     for (int s = 0; s < TW_NS - 1; ++s)
@@ -213,7 +218,9 @@ __global__ __launch_bounds__(TW_THREADS, 2) void gemm_tn_wide_kernel(const GemmT
                 __builtin_amdgcn_s_barrier();          // every wave's part of stage kt is in LDS; stage kt-1 has been consumed
                 if (ragged && kt == nk - 1) {
                     const int valid = (m_end - m_begin) - kt * TW_BK;          // rows of this stage inside the matrix
-                    for (int e = tid; e < NIA * (TW_BK - valid) * 8; e += TW_THREADS) {
+                    // (A panels: the products vanish; with exchanged operands the column sums run over the B panels: those too)
+                    const int nimg = g.swapped ? NIA + NIB : NIA;
+                    for (int e = tid; e < nimg * (TW_BK - valid) * 8; e += TW_THREADS) {
                         const int img = e / ((TW_BK - valid) * 8), rem = e - img * ((TW_BK - valid) * 8);
                         *reinterpret_cast<uint4*>(smem + s * STAGE + img * TW_IMG + (valid + (rem >> 3)) * 128 + (rem & 7) * 16) =
                             make_uint4(0, 0, 0, 0);
@@ -240,6 +247,12 @@ __global__ __launch_bounds__(TW_THREADS, 2) void gemm_tn_wide_kernel(const GemmT
                     }
                     const bf16x8 bj = tw_join(blo[j % 3], bhi[j % 3]);
                     TW_FOR(FM, i, acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bj, af[i], acc[i][j], 0, 0, 0););
+                    if (do_colsum_b) {
+                        const i32x4 wb = __builtin_bit_cast(i32x4, bj);
+                        float cb = csum_b[j];
+                        cb = tw_dot2_ones(wb[0], cb); cb = tw_dot2_ones(wb[1], cb); cb = tw_dot2_ones(wb[2], cb); cb = tw_dot2_ones(wb[3], cb);
+                        csum_b[j] = cb;
+                    }
                     if (j + 2 < FN) tw_read_frag<(((j + 2) * W2) >> 2) * TW_IMG>(rb[(j + 2) % NVB], blo[(j + 2) % 3], bhi[(j + 2) % 3]);
                 );
                 if (do_colsum) {
@@ -264,6 +277,16 @@ __global__ __launch_bounds__(TW_THREADS, 2) void gemm_tn_wide_kernel(const GemmT
             if (lg == 0 && n1 < g.N1) atomicAdd(g.colsum_a + n1, v * g.alpha);
         }
     }
+    if (do_colsum_b) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            float v = csum_b[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n2 = c2 + (j * W2 + w2) * 16 + li;
+            if (lg == 0 && n2 < g.N2) atomicAdd(g.colsum_a + n2, v * g.alpha);
+        }
+    }
     // swapped issue: lane (li, lg) holds C[n1 = .. + li][n2 = .. + 4 lg + 0..3]; the FM*16 tile rows of one wave row (16-row blocks
     // i*W1 + w1) at a time go through LDS and leave as 256-byte contiguous atomic rows
     float* Cs = reinterpret_cast<float*>(smem);
@@ -278,10 +301,18 @@ __global__ __launch_bounds__(TW_THREADS, 2) void gemm_tn_wide_kernel(const GemmT
                     *reinterpret_cast<f32x4*>(Cs + (i * 16 + li) * LDCS + (j * W2 + w2) * 16 + 4 * lg) = acc[i][j];
         }
         __syncthreads();
-        for (int idx = tid; idx < FM * 16 * T2; idx += TW_THREADS) {
-            const int r = idx / T2, c = idx - r * T2;
-            const int gr = c1 + ((r >> 4) * W1 + sl) * 16 + (r & 15), gc = c2 + c;
-            if (gr < g.N1 && gc < g.N2) atomicAdd(g.C + (size_t)gr * g.ldc + gc, Cs[r * LDCS + c] * g.alpha);
+        if (!g.swapped) {
+            for (int idx = tid; idx < FM * 16 * T2; idx += TW_THREADS) {
+                const int r = idx / T2, c = idx - r * T2;
+                const int gr = c1 + ((r >> 4) * W1 + sl) * 16 + (r & 15), gc = c2 + c;
+                if (gr < g.N1 && gc < g.N2) atomicAdd(g.C + (size_t)gr * g.ldc + gc, Cs[r * LDCS + c] * g.alpha);
+            }
+        } else {                 // the caller's matrix is [N2, N1]: 16 consecutive rows of the staged block are 64 contiguous bytes of it
+            for (int idx = tid; idx < FM * 16 * T2; idx += TW_THREADS) {
+                const int c = idx / (FM * 16), r = idx - c * (FM * 16);
+                const int gr = c1 + ((r >> 4) * W1 + sl) * 16 + (r & 15), gc = c2 + c;
+                if (gr < g.N1 && gc < g.N2) atomicAdd(g.C + (size_t)gc * g.ldc + gr, Cs[r * LDCS + c] * g.alpha);
+            }
         }
     }
 }
@@ -311,11 +342,24 @@ bool mmg_tn_wide_launch(GemmTN& g, hipStream_t stream) {
     // every workgroup flushes a whole tile with fp32 atomics (75 MB per launch at 256 workgroups of 192 x 384 = ~60 us): only
     // reductions long enough to amortise that take this kernel
     if (g.M < min_m || g.N1 < 96 || g.N2 < 96) return false;
-    const bool wide2 = g.N2 >= g.N1;                 // orientation: the wider side gets the 384 (or the 4 wave columns)
+    const bool wide2 = g.N2 >= g.N1;                 // orientation: the wider side gets the 384 (the 4 wave columns)
     const int narrow = wide2 ? g.N1 : g.N2, wideN = wide2 ? g.N2 : g.N1;
     const int tn = narrow <= 96 ? 96 : 192;
     const double waste = (double)(cdiv(narrow, tn) * tn) * (cdiv(wideN, 384) * 384) / ((double)narrow * wideN);
     if (waste > 1.2) return false;                   // badly fitting widths stay on the 128-wide tiles of gemm_bf16.hip
+    // N1 > N2 (dW1 = dh^T x of a CNBlock: [4C, C]) runs as its transpose: operands exchanged, tile flushed transposed, bias sums taken
+    // from the B fragments.  Same-run A/B against the mirrored instantiations <384, 192> / <384, 96> (profiles/r02_tn_wide_swap_ab.txt):
+    // equal on the stage-1/2 shapes, 2-3 % faster on 1536 x 384; MMG_TN_WIDE_MIRROR=1 brings the mirrored ones back.
+    static const int mirror = getenv("MMG_TN_WIDE_MIRROR") ? atoi(getenv("MMG_TN_WIDE_MIRROR")) : 0;
+    g.swapped = 0;
+    if (!wide2 && !mirror) {
+        const bf16_t* t = g.A; g.A = g.B; g.B = t;
+        int x = g.N1; g.N1 = g.N2; g.N2 = x;
+        x = g.lda; g.lda = g.ldb; g.ldb = x;
+        g.swapped = 1;
+        if (tn == 96) launch_tw<96, 384>(g, stream); else launch_tw<192, 384>(g, stream);
+        return true;
+    }
     if (wide2) { if (tn == 96) launch_tw<96, 384>(g, stream); else launch_tw<192, 384>(g, stream); }
     else       { if (tn == 96) launch_tw<384, 96>(g, stream); else launch_tw<384, 192>(g, stream); }
     return true;

@@ -170,10 +170,13 @@ def test_nt_fp8_rejects_bad_k(dev):
 
 
 # ---- wide-tile weight-gradient kernel (gemm_tn_wide.hip: M >= 65536, widths that fit 96/192 x 384) ---------------------------
-def test_tn_wide_integer_exact_asymmetric(dev):
-    """Every configuration of the 8-wave kernel on exact small integers (fp32 sums stay exact): 192x384, 384x192, 96x384, 384x96
-    tiles, several tiles per side, asymmetric operands (a transposed or mis-swizzled fragment cannot pass)."""
+@pytest.mark.parametrize("mirror", ["0", "1"])
+def test_tn_wide_integer_exact_asymmetric(dev, mirror, monkeypatch):
+    """Every configuration of the 8-wave kernel on exact small integers (fp32 sums stay exact): 192x384, 96x384 tiles, N1 > N2 shapes
+    both as the exchanged-operand / transposed-flush form (default) and on the mirrored 384x192 / 384x96 instantiations
+    (MMG_TN_WIDE_MIRROR=1), several tiles per side, asymmetric operands (a transposed or mis-swizzled fragment cannot pass)."""
     from mmgclip import linalg
+    monkeypatch.setenv("MMG_TN_WIDE_MIRROR", mirror)
     for M, N1, N2 in ((65536, 192, 384), (65536 + 32, 384, 192), (70000, 96, 384), (65568, 384, 96), (66000, 384, 768), (65536, 768, 384)):
         g = torch.Generator().manual_seed(M + N1)
         a = torch.randint(-2, 3, (M, N1), generator=g).float()
