@@ -218,6 +218,7 @@ def main():
                     if tower is not None:
                         tower.post_backward_hook = sync.reduce_arena_async
         loss.backward()
+        model.join_streams()                  # (two-stream mode, MMG_TEXT_STREAM=1: the text tower's backward ran on a side stream)
         sync.finish()
         if optimizer is None:
             optimizer = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.optimizer.config.learning_rate,

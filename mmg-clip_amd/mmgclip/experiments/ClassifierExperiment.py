@@ -129,6 +129,8 @@ class ClassifierExperiment:
             loss, labels = self.criterion(**outputs)
             sync = self._grad_sync() if parallel else None      # (installs the towers' post-backward hooks on first use)
             loss.backward()
+            if hasattr(self.model, "join_streams"):
+                self.model.join_streams()                       # (two-stream mode: the text tower's backward ran on a side stream)
             if sync is not None:
                 sync.finish()                                   # every gradient is the all-rank sum before the optimizer reads it
             self.optimizer.step()

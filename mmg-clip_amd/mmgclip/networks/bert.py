@@ -383,6 +383,8 @@ class _BertFn(torch.autograd.Function):
     def backward(ctx, dh):
         tower = ctx.tower
         tower._arena.prepare_grads()
+        if dh.is_cuda:                       # (two-stream mode: the gradient was produced on another stream than this backward's)
+            dh.record_stream(torch.cuda.current_stream())
         dh = dh.to(torch.bfloat16).contiguous()
         row = 0
         for k, sv in enumerate(ctx.saved_mb):
@@ -391,7 +393,10 @@ class _BertFn(torch.autograd.Function):
             row += B * S
         ctx.saved_mb = None
         backward_finished(tower)
-        return None, None, None, None, None, None
+        # The anchor gets a (zero) gradient so that autograd accumulates on THIS stream: the engine then makes the caller's stream wait
+        # for it at the end of backward() - in two-stream mode (mmgclip_model.py) the parameter gradients written above are complete for
+        # whoever reads them next, with or without an explicit MMGCLIP.join_streams().
+        return None, None, None, None, torch.zeros(1, device=dh.device), None
 
 
 class EosPool(torch.autograd.Function):
@@ -407,6 +412,8 @@ class EosPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
+        if dout.is_cuda:
+            dout.record_stream(torch.cuda.current_stream())
         return K.eos_pool_bwd(dout.float().contiguous(), idx, ctx.B, ctx.S), None, None, None
 
 

@@ -217,3 +217,44 @@ def test_ragged_and_degenerate_batches(dev, monkeypatch, n, S):
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     fused, _ = create_loss("CLIPLoss")()(**model(batch, materialize_logits=False))
     assert abs(fused.item() - loss.item()) < 1e-4 * max(abs(loss.item()), 0.1)
+
+
+def test_two_stream_towers_give_the_same_step(dev, monkeypatch):
+    """The default runs the text tower (forward and, through autograd's stream replay, backward) on a side stream next to the image
+    tower; MMG_TEXT_STREAM=0 keeps everything on one stream: the loss is bit-identical and every gradient equal up to the atomics'
+    summation order."""
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    _small_bert(monkeypatch)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MMG_TEXT_STREAM", mode)
+        torch.manual_seed(0)
+        cfg = _cfg("networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_seqlen=77", "networks/dropout=dropout0",
+                   "networks.image_encoder.micro_batch=4", "networks.image_encoder.image_size=64")
+        model = MMGCLIP(cfg).train()
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith("layer_scale"):
+                    p.fill_(0.5)
+        crit = create_loss("CLIPLoss")()
+        losses = []
+        for step in range(3):                                      # a few steps back to back: stream hand-overs in both directions
+            batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=4 + step)
+            model.zero_grad(set_to_none=True)
+            loss, _ = crit(**model(batch, materialize_logits=False))
+            loss.backward()
+            if step < 2:
+                model.join_streams()
+            losses.append(loss.item())
+        # last step WITHOUT join_streams(), as in the reference's loop (backward(); optimizer.step()): autograd itself must have made
+        # this stream wait for the side stream (the text tower's backward hands its anchor a gradient for exactly that)
+        torch.cuda.current_stream().synchronize()
+        assert (model._text_stream() is not None) == (mode == "1")
+        res[mode] = (losses, {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert res["0"][0] == res["1"][0], (res["0"][0], res["1"][0])
+    assert res["0"][1].keys() == res["1"][1].keys()
+    for n, g0 in res["0"][1].items():
+        g1 = res["1"][1][n]
+        assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max()) + 1e-9, n
