@@ -154,9 +154,15 @@ class MMGCLIP(nn.Module):
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)                                   # parameters updated by the optimizer, tokens copied by the caller
+            # the image tower is enqueued first: its large kernels keep the GPU busy while the host is still launching the text
+            # tower's several hundred small ones (MMG_TEXT_FIRST=1: the other order, for A/B runs)
+            text_first = os.environ.get("MMG_TEXT_FIRST", "0") == "1"
+            if not text_first:
+                image_features = self.encode_images(batch)
             with torch.cuda.stream(side):
                 text_features = self.encode_text(batch, text_pooling='eos')
-            image_features = self.encode_images(batch)
+            if text_first:
+                image_features = self.encode_images(batch)
             main.wait_stream(side)
             text_features.record_stream(main)
         else:
