@@ -176,3 +176,46 @@ def test_bert_tower_dropout_switches(dev, monkeypatch):
     enc.dropout = True
     monkeypatch.setenv("MMG_BERT_DROPOUT", "0")
     assert torch.equal(run(), e0)
+
+
+def test_whole_model_step_with_dropout_is_the_same_on_one_or_two_streams(dev, monkeypatch):
+    """Product defaults together: HF training-mode dropout live in the text tower AND the text tower on its side stream.  With the
+    same torch seed the masks are the same, so the one-stream run must give the same losses and gradients; and a second run with the
+    same seed reproduces the first bit for bit in the loss."""
+    from tests.test_model_gpu import _cfg, _small_bert
+    from mmgclip.dataset.synthetic import synthetic_batch
+    from mmgclip.loss.loss_controller import create_loss
+    from mmgclip.networks.mmgclip_model import MMGCLIP
+    _small_bert(monkeypatch)
+    res = {}
+    for tag, stream in (("two", "1"), ("one", "0"), ("two_again", "1")):
+        monkeypatch.setenv("MMG_TEXT_STREAM", stream)
+        torch.manual_seed(0)
+        cfg = _cfg("networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_seqlen=77", "networks/dropout=dropout0",
+                   "networks.image_encoder.micro_batch=4", "networks.image_encoder.image_size=64", "loss.config.loss_name=MMGCLIPLoss")
+        model = MMGCLIP(cfg).train()
+        assert model.text_encoder.dropout and model.text_encoder.training
+        crit = create_loss("MMGCLIPLoss")()
+        torch.manual_seed(123)                                     # the dropout seeds of the steps below come from this generator
+        losses = []
+        for step in range(2):
+            batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=9 + step, with_impression=True)
+            model.zero_grad(set_to_none=True)
+            loss, _ = crit(**model(batch, materialize_logits=False))
+            loss.backward()
+            losses.append(loss.item())
+        torch.cuda.current_stream().synchronize()
+        res[tag] = (losses, {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert res["two"][0] == res["one"][0] == res["two_again"][0], (res["two"][0], res["one"][0], res["two_again"][0])
+    for n, g0 in res["one"][1].items():
+        g1 = res["two"][1][n]
+        assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max()) + 1e-9, n
+    # and dropout really is on: the deterministic tower gives another loss
+    monkeypatch.setenv("MMG_BERT_DROPOUT", "0")
+    torch.manual_seed(0)
+    model = MMGCLIP(_cfg("networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_seqlen=77", "networks/dropout=dropout0",
+                         "networks.image_encoder.micro_batch=4", "networks.image_encoder.image_size=64",
+                         "loss.config.loss_name=MMGCLIPLoss")).train()
+    batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=9, with_impression=True)
+    loss, _ = create_loss("MMGCLIPLoss")()(**model(batch, materialize_logits=False))
+    assert abs(loss.item() - res["two"][0][0]) > 1e-4
