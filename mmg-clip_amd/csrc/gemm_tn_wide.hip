@@ -30,6 +30,9 @@ template <> struct TwCfg<192, 384> { static constexpr int W1 = 2, W2 = 4, FM = 6
 template <> struct TwCfg<384, 192> { static constexpr int W1 = 4, W2 = 2, FM = 6, FN = 6; };
 template <> struct TwCfg<96, 384>  { static constexpr int W1 = 1, W2 = 8, FM = 6, FN = 3; };
 template <> struct TwCfg<384, 96>  { static constexpr int W1 = 8, W2 = 1, FM = 3, FN = 6; };
+// ConvNeXt-B widths (128 / 256 / 512 / 1024): 256-wide tiles, 64 / 128 accumulator registers per lane
+template <> struct TwCfg<128, 256> { static constexpr int W1 = 2, W2 = 4, FM = 4, FN = 4; };
+template <> struct TwCfg<256, 256> { static constexpr int W1 = 2, W2 = 4, FM = 8, FN = 4; };
 
 // physical 16-byte slot (0..7) of logical chunk c in reduction row m of a panel
 __device__ __forceinline__ int tw_swz(int m, int c) {
@@ -342,25 +345,41 @@ bool mmg_tn_wide_launch(GemmTN& g, hipStream_t stream) {
     // every workgroup flushes a whole tile with fp32 atomics (75 MB per launch at 256 workgroups of 192 x 384 = ~60 us): only
     // reductions long enough to amortise that take this kernel
     if (g.M < min_m || g.N1 < 96 || g.N2 < 96) return false;
-    const bool wide2 = g.N2 >= g.N1;                 // orientation: the wider side gets the 384 (the 4 wave columns)
+    const bool wide2 = g.N2 >= g.N1;                 // orientation: the wider side gets the wide tile edge (the 4 wave columns)
     const int narrow = wide2 ? g.N1 : g.N2, wideN = wide2 ? g.N2 : g.N1;
-    const int tn = narrow <= 96 ? 96 : 192;
-    const double waste = (double)(cdiv(narrow, tn) * tn) * (cdiv(wideN, 384) * 384) / ((double)narrow * wideN);
-    if (waste > 1.2) return false;                   // badly fitting widths stay on the 128-wide tiles of gemm_bf16.hip
+    // tile = (narrow edge, wide edge) with the least padding: 96 / 192 x 384 (ConvNeXt-T widths), 128 / 256 x 256 (ConvNeXt-B widths)
+    static const int cfgs[4][2] = {{96, 384}, {192, 384}, {128, 256}, {256, 256}};
+    int best = -1;
+    double best_waste = 1e9;
+    for (int i = 0; i < 4; ++i) {
+        const double w = (double)(cdiv(narrow, cfgs[i][0]) * cfgs[i][0]) * (cdiv(wideN, cfgs[i][1]) * cfgs[i][1]) / ((double)narrow * wideN);
+        if (w < best_waste - 1e-9) { best_waste = w; best = i; }
+    }
+    static const int allow_b = getenv("MMG_TN_WIDE_B") ? atoi(getenv("MMG_TN_WIDE_B")) : 1;     // 0: the 256-wide tiles off (A/B runs)
+    if (!allow_b && best >= 2) {
+        best = narrow <= 96 ? 0 : 1;
+        best_waste = (double)(cdiv(narrow, cfgs[best][0]) * cfgs[best][0]) * (cdiv(wideN, 384) * 384) / ((double)narrow * wideN);
+    }
+    if (best_waste > 1.2) return false;              // badly fitting widths stay on the 128-wide tiles of gemm_bf16.hip
+    const int tn = cfgs[best][0];
     // N1 > N2 (dW1 = dh^T x of a CNBlock: [4C, C]) runs as its transpose: operands exchanged, tile flushed transposed, bias sums taken
     // from the B fragments.  Same-run A/B against the mirrored instantiations <384, 192> / <384, 96> (profiles/r02_tn_wide_swap_ab.txt):
     // equal on the stage-1/2 shapes, 2-3 % faster on 1536 x 384; MMG_TN_WIDE_MIRROR=1 brings the mirrored ones back.
     static const int mirror = getenv("MMG_TN_WIDE_MIRROR") ? atoi(getenv("MMG_TN_WIDE_MIRROR")) : 0;
     g.swapped = 0;
-    if (!wide2 && !mirror) {
+    if (!wide2 && !(mirror && best < 2)) {
         const bf16_t* t = g.A; g.A = g.B; g.B = t;
         int x = g.N1; g.N1 = g.N2; g.N2 = x;
         x = g.lda; g.lda = g.ldb; g.ldb = x;
         g.swapped = 1;
-        if (tn == 96) launch_tw<96, 384>(g, stream); else launch_tw<192, 384>(g, stream);
-        return true;
     }
-    if (wide2) { if (tn == 96) launch_tw<96, 384>(g, stream); else launch_tw<192, 384>(g, stream); }
-    else       { if (tn == 96) launch_tw<384, 96>(g, stream); else launch_tw<384, 192>(g, stream); }
+    if (g.swapped || wide2) {
+        if (best == 0) launch_tw<96, 384>(g, stream);
+        else if (best == 1) launch_tw<192, 384>(g, stream);
+        else if (best == 2) launch_tw<128, 256>(g, stream);
+        else launch_tw<256, 256>(g, stream);
+    } else {
+        if (tn == 96) launch_tw<384, 96>(g, stream); else launch_tw<384, 192>(g, stream);
+    }
     return true;
 }

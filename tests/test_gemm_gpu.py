@@ -177,7 +177,8 @@ def test_tn_wide_integer_exact_asymmetric(dev, mirror, monkeypatch):
     (MMG_TN_WIDE_MIRROR=1), several tiles per side, asymmetric operands (a transposed or mis-swizzled fragment cannot pass)."""
     from mmgclip import linalg
     monkeypatch.setenv("MMG_TN_WIDE_MIRROR", mirror)
-    for M, N1, N2 in ((65536, 192, 384), (65536 + 32, 384, 192), (70000, 96, 384), (65568, 384, 96), (66000, 384, 768), (65536, 768, 384)):
+    for M, N1, N2 in ((65536, 192, 384), (65536 + 32, 384, 192), (70000, 96, 384), (65568, 384, 96), (66000, 384, 768), (65536, 768, 384),
+                      (65536, 128, 512), (65600, 512, 128), (66000, 256, 1024), (65536 + 64, 1024, 256), (65536, 512, 2048)):   # ConvNeXt-B widths
         g = torch.Generator().manual_seed(M + N1)
         a = torch.randint(-2, 3, (M, N1), generator=g).float()
         b = torch.randint(-1, 2, (M, N2), generator=g).float()
@@ -191,7 +192,8 @@ def test_tn_wide_integer_exact_asymmetric(dev, mirror, monkeypatch):
 
 
 @pytest.mark.parametrize("M,N1,N2", [(65536, 96, 384), (131072 + 17, 384, 96), (70001, 192, 768), (65536 * 3, 768, 192), (262144, 384, 1536),
-                                     (100000, 768, 3072), (65536, 128, 512), (65599, 200, 392), (80000, 1024, 256)])
+                                     (100000, 768, 3072), (65536, 128, 512), (65599, 200, 392), (80000, 1024, 256), (70003, 512, 128),
+                                     (65537, 256, 1024), (66001, 2048, 512)])
 def test_tn_wide(dev, M, N1, N2, monkeypatch):
     """Random data incl. ragged M (last stage partly beyond the matrix), widths that need clamped panels (128, 200, 392) and
     shapes the dispatcher must leave to the 128-wide kernel; both kernels must agree with fp64."""
