@@ -91,8 +91,11 @@ class ConvNextTower(nn.Module):
         # narrow stages (C <= 256) run the CNBlock MLP as one fused launch; MMG_FUSED_MLP=0 keeps the GEMM pair
         self.fused_mlp = (os.environ.get("MMG_FUSED_MLP", "1") != "0") if fused_mlp is None else bool(fused_mlp)
         self.fused_bwd_saved_h = os.environ.get("MMG_FUSED_MLP_BWD_SAVED_H", "0") == "1"
-        # blocks whose backward is the GEMM pair keep their LayerNorm output ([M,C] bf16) instead of recomputing it (A/B: MMG_SAVE_LN=0)
-        self.save_ln = os.environ.get("MMG_SAVE_LN", "1") != "0"
+        # blocks whose backward is the GEMM pair keep their LayerNorm output ([M,C] bf16) instead of recomputing it - decided per forward:
+        # only while those copies stay below 4 % of the device memory (C2: 8.4 GB on; ConvNeXt-B at 256 images without checkpointing:
+        # 31 GB on top of 267 GiB of activations, off).  MMG_SAVE_LN=0 / 1 force it.
+        self.save_ln_mode = os.environ.get("MMG_SAVE_LN", "auto")
+        self.save_ln = self.save_ln_mode == "1"
         self.checkpoint = checkpoint        # recompute each micro-batch's forward in the backward (north-star config C5)
         # fp8 (config C5): the two pointwise GEMMs of every block with C % 128 == 0 and C >= fp8_min_channels run their FORWARD
         # on e4m3 operands (LayerNorm / GELU outputs cast unscaled, weights with a per-tensor power-of-two scale); the backward
@@ -163,6 +166,18 @@ class ConvNextTower(nn.Module):
                 wc[f"ds{si}.w"] = K.cast_bf16(wds)
                 wc[f"ds{si}.wt"] = K.transpose_cast_bf16(wds)
         self._wc, self._wc_version = wc, v
+
+    def _decide_save_ln(self, n_alive, H, W, device):
+        """n_alive = images whose saved tensors are alive at once (the whole batch; one micro-batch under checkpointing)."""
+        if self.save_ln_mode in ("0", "1"):
+            return self.save_ln_mode == "1"
+        extra, hh, ww = 0, H // 4, W // 4
+        for si in range(4):
+            C = self.dims[si]
+            if not (K.cnblock_supported(C) and K.cnblock_bwd_mode(C) == 1) and not (K.cnblock_bwd_mode(C) == 2 and self.fused_bwd_saved_h):
+                extra += self.depths[si] * n_alive * hh * ww * C * 2
+            hh, ww = hh // 2, ww // 2
+        return extra <= 0.04 * torch.cuda.get_device_properties(device).total_memory
 
     # ---- forward / backward over one micro-batch -----------------------------------------------------------
     def _forward_mb(self, img, save):
@@ -366,6 +381,9 @@ class _ConvNextFn(torch.autograd.Function):
         feats, saved = [], []
         mb = tower.micro_batch
         ckpt = save and tower.checkpoint
+        if save:
+            tower.save_ln = tower._decide_save_ln(min(mb, images.shape[0]) if ckpt else images.shape[0], images.shape[-2], images.shape[-1],
+                                                  images.device)
         for i in range(0, images.shape[0], mb):
             ft, sv = tower._forward_mb(images[i:i + mb], save and not ckpt)
             feats.append(ft)

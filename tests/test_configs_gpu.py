@@ -170,3 +170,14 @@ def test_mmgclip_loss_gradients_match_reference_golden(dev, golden_dir, n):
         err = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
         assert err < 2e-4, (key, err)
     assert abs(ls.grad.item() - float(g["mmg_dlogit_scale"])) < 2e-4 * max(abs(float(g["mmg_dlogit_scale"])), 1e-3)
+
+
+def test_saved_layernorm_output_is_bounded_by_device_memory(dev):
+    """The GEMM-pair-backward blocks keep their LayerNorm output only while those copies stay below 4 % of the device memory:
+    on for BASELINE config C2 (8.4 GB), off for ConvNeXt-B at 256 images without checkpointing (it would not fit beside its 267 GiB
+    of activations), on again for one of its 64-image checkpointed micro-batches."""
+    from mmgclip.networks.encoder import ConvNextBaseEncoder, ConvNextTinyEncoder
+    tiny, base = ConvNextTinyEncoder(), ConvNextBaseEncoder()
+    assert tiny._decide_save_ln(256, 1024, 1024, dev) is True
+    assert base._decide_save_ln(256, 1024, 1024, dev) is False
+    assert base._decide_save_ln(64, 1024, 1024, dev) is True
