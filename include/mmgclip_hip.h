@@ -318,7 +318,7 @@ int mmg_attention_varlen_bwd(const void* qkv, int ld, const int* cu_seqlens, con
  * attention_probs_dropout_prob = 0.1 (notebooks/bert_experimental.ipynb:609-624).  Masks are counter-based (csrc/dropout.h;
  * restated in oracle/dropout_oracle.py): element `index` of dropout site `site` is kept, and scaled by 1/(1-p), iff
  * fmix32(index * 0x9E3779B1 + key(seed, site)) >= floor(p * 2^32) - the backward regenerates the mask from (p, seed, site).
- *   mmg_attention_dropout_fwd/_bwd: the whole-sequence attention above (S <= 512 forward, <= 256 backward) with the
+ *   mmg_attention_dropout_fwd/_bwd: the whole-sequence attention above (S <= 512 forward, <= 256 backward; _long_bwd beyond) with the
  *     probabilities dropped before P V; cu_seqlens != NULL selects the packed layout (then `mask` is unused), else the padded one.
  *     index = (((first_sequence + b) * heads + h) * 512 + query) * 512 + key  (first_sequence: position of this call's
  *     sequence 0 in the whole batch, so that micro-batches of one batch draw disjoint masks).
@@ -332,6 +332,11 @@ int mmg_attention_dropout_bwd(const void* qkv, int ld, const long long* mask, co
                               const float* lse, const void* dctx, int lddc, void* dqkv, int lddq, int B, int S, int heads,
                               int Hd, float scale, float p, unsigned long long seed, unsigned site, int first_sequence,
                               mmg_stream_t stream);
+/* the same backward for 256 < S <= 512 (padded layout only): tiled dQ / dK,dV kernels; delta_ws = fp32 [B * heads * S] workspace */
+int mmg_attention_dropout_long_bwd(const void* qkv, int ld, const long long* mask, const void* ctx, int ldc, const float* lse,
+                                   const void* dctx, int lddc, void* dqkv, int lddq, float* delta_ws, int B, int S, int heads,
+                                   int Hd, float scale, float p, unsigned long long seed, unsigned site, int first_sequence,
+                                   mmg_stream_t stream);
 int mmg_dropout_f32(float* x, int ldx, void* xb, int ldb, const long long* rows, long long M, int C, float p,
                     unsigned long long seed, unsigned site, mmg_stream_t stream);
 int mmg_dropout_bf16(const void* in, int ldi, void* out, int ldo, const long long* rows, long long M, int C, float p,

@@ -688,7 +688,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // dQ of RB x 64 query rows per workgroup: K / V tiles stream through LDS; p = exp2(s c2 - lse log2e), dS = p (dP - delta) scale
-template <int RB, bool MASK>
+// DROP (BERT training at 256 < S <= 512): dP = mask (dO V^T) / (1 - p), as in attn_bwd_kernel<true>
+template <int RB, bool MASK, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const AttArgs a, const float* __restrict__ delta) {
     __shared__ __attribute__((aligned(16))) char KV[2][2][ATT_TILE * 128];
     int bh, qb;
@@ -758,7 +759,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const AttArgs a, 
                     for (int r = 0; r < 4; ++r) {
                         float pv = att_exp2(fmaf(sv[r], c2, -lq2[rb]));
                         pv = ok[r] ? pv : 0.f;
-                        ds[rb][t2][r] = pv * (dp[r] - dl[rb]) * a.scale;
+                        const float dpr = DROP ? att_drop(dp[r], bh + a.bh0, q0 + rb * 16 + li, k0 + t * 16 + 4 * g + r, a.drop) : dp[r];
+                        ds[rb][t2][r] = pv * (dpr - dl[rb]) * a.scale;
                     }
                 }
             }
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const AttArgs a, 
 }
 
 // dK, dV of RB x 64 keys per workgroup: Q / dO tiles (+ their lse, delta) stream through LDS
-template <int RB, bool MASK>
+template <int RB, bool MASK, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_flash_dkv_kernel(const AttArgs a, const float* __restrict__ delta) {
     __shared__ __attribute__((aligned(16))) char QG[2][2][ATT_TILE * 128];
     __shared__ __attribute__((aligned(16))) float lses[2][ATT_TILE];
@@ -863,8 +865,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkv_kernel(const AttArgs a,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = kok[rb] ? att_exp2(fmaf(sv[r], c2, -lq[r])) : 0.f;
-                        pp[rb][t2][r] = pv;
-                        ds[rb][t2][r] = pv * (dp[r] - dl[r]) * a.scale;
+                        // (row of this accumulator = query qt * 64 + ql + 4 g + r, column = key kbase + 16 rb + li)
+                        pp[rb][t2][r] = DROP ? att_drop(pv, bh + a.bh0, qt * ATT_TILE + ql + 4 * g + r, kbase + rb * 16 + li, a.drop) : pv;
+                        const float dpr = DROP ? att_drop(dp[r], bh + a.bh0, qt * ATT_TILE + ql + 4 * g + r, kbase + rb * 16 + li, a.drop) : dp[r];
+                        ds[rb][t2][r] = pv * (dpr - dl[r]) * a.scale;
                     }
                 }
             }
@@ -975,5 +979,41 @@ MMG_API int mmg_attention_long_bwd(const void* qkv, int ld, const long long* mas
     if (rbk == 3) ATT_BWD(attn_flash_dkv_kernel, 3); else if (rbk == 2) ATT_BWD(attn_flash_dkv_kernel, 2); else ATT_BWD(attn_flash_dkv_kernel, 1);
 #undef ATT_BWD
     MMG_LAUNCH_CHECK("mmg_attention_long_bwd");
+    return 0;
+}
+
+// Backward of mmg_attention_dropout_fwd for 256 < S <= 512 (padded layout): the tiled dQ / dK,dV kernels with the same mask.
+// delta_ws: caller-provided fp32 workspace of B * heads * S elements.
+MMG_API int mmg_attention_dropout_long_bwd(const void* qkv, int ld, const long long* mask, const void* ctx, int ldc, const float* lse,
+                                           const void* dctx, int lddc, void* dqkv, int lddq, float* delta_ws, int B, int S, int heads,
+                                           int Hd, float scale, float p, unsigned long long seed, unsigned site, int first_sequence,
+                                           hipStream_t stream) {
+    if (att_check("mmg_attention_dropout_long_bwd", B, S, heads, Hd, ld, 512)) return 1;
+    MMG_CHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta_ws && ldc >= Hd && lddc >= Hd && lddq >= 3 * Hd && ldc % 8 == 0 &&
+                      lddc % 8 == 0 && lddq % 8 == 0, "mmg_attention_dropout_long_bwd: bad pointer or leading dimension");
+    MMG_CHECK_ARG(first_sequence >= 0, "mmg_attention_dropout_long_bwd: first_sequence %d", first_sequence);
+    AttArgs a = {};
+    a.qkv = (const bf16_t*)qkv; a.ld = ld; a.mask = mask; a.ctx = (bf16_t*)ctx; a.ldc = ldc; a.lse = const_cast<float*>(lse);
+    a.S = S; a.S_pad = cdiv(S, 32) * 32; a.heads = heads; a.Hd = Hd; a.scale = scale;
+    a.dctx = (const bf16_t*)dctx; a.lddc = lddc; a.dqkv = (bf16_t*)dqkv; a.lddq = lddq;
+    if (att_drop_args("mmg_attention_dropout_long_bwd", p, seed, site, a.drop)) return 1;
+    a.bh0 = first_sequence * heads;
+    long rows = (long)B * S * heads;
+    int blocks = (int)((rows + 31) / 32 > 8192 ? 8192 : (rows + 31) / 32);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)ctx, ldc, (const bf16_t*)dctx, lddc,
+                       delta_ws, B, S, heads);
+    const long bhn = (long)B * heads;
+    const float* dws = (const float*)delta_ws;
+    a.nbh = (int)bhn;
+    a.nblk = cdiv(S, 64 * 2);                        // two row blocks per wave in both kernels (S <= 512: 128-row workgroups)
+    const dim3 grid((unsigned)(bhn * a.nblk));
+    if (mask) {
+        hipLaunchKernelGGL((attn_flash_dq_kernel<2, true, true>), grid, dim3(256), 0, stream, a, dws);
+        hipLaunchKernelGGL((attn_flash_dkv_kernel<2, true, true>), grid, dim3(256), 0, stream, a, dws);
+    } else {
+        hipLaunchKernelGGL((attn_flash_dq_kernel<2, false, true>), grid, dim3(256), 0, stream, a, dws);
+        hipLaunchKernelGGL((attn_flash_dkv_kernel<2, false, true>), grid, dim3(256), 0, stream, a, dws);
+    }
+    MMG_LAUNCH_CHECK("mmg_attention_dropout_long_bwd");
     return 0;
 }

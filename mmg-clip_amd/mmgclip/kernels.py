@@ -233,9 +233,16 @@ def attention_dropout_fwd(qkv, mask, B, S, heads, p, seed, site, want_lse=True, 
 
 
 def attention_dropout_bwd(qkv, mask, ctx, lse, dctx, B, S, heads, p, seed, site, cu=None, first_sequence=0):
-    """Backward of attention_dropout_fwd (same p, seed, site): S <= 256."""
+    """Backward of attention_dropout_fwd (same p, seed, site): whole-sequence kernel up to S = 256, tiled kernels up to 512 (padded)."""
     Hd = heads * 64
     dqkv = torch.empty(qkv.shape[0], 3 * Hd, device=qkv.device, dtype=BF16)
+    if S > 256:
+        assert cu is None, "the packed layout is used up to S = 256 only"
+        delta = torch.empty(B * heads * S, device=qkv.device, dtype=torch.float32)
+        call("mmg_attention_dropout_long_bwd", ptr(qkv), qkv.stride(0), ptr(mask), ptr(ctx), ctx.stride(0), ptr(lse), ptr(dctx),
+             dctx.stride(0), ptr(dqkv), dqkv.stride(0), ptr(delta), B, S, heads, Hd, 0.125, float(p), int(seed), int(site),
+             int(first_sequence), stream())
+        return dqkv
     call("mmg_attention_dropout_bwd", ptr(qkv), qkv.stride(0), ptr(mask) if cu is None else None, ptr(cu), ptr(ctx), ctx.stride(0),
          ptr(lse), ptr(dctx), dctx.stride(0), ptr(dqkv), dqkv.stride(0), B, S, heads, Hd, 0.125, float(p), int(seed), int(site),
          int(first_sequence), stream())

@@ -214,11 +214,11 @@ class BertTower(nn.Module):
     _warned_long_attention_dropout = False
 
     def _attention_dropout_ok(self, S):
-        if S <= 256:
+        if S <= 512:                         # (= max_position_embeddings of the reference's BERT: every length it can run)
             return True
         if not BertTower._warned_long_attention_dropout:
             import warnings
-            warnings.warn(f"attention-probability dropout is implemented for S <= 256 (got S = {S}): skipped; the hidden-state "
+            warnings.warn(f"attention-probability dropout is implemented for S <= 512 (got S = {S}): skipped; the hidden-state "
                           "dropouts stay on")
             BertTower._warned_long_attention_dropout = True
         return False
