@@ -348,7 +348,8 @@ bool mmg_tn_wide_launch(GemmTN& g, hipStream_t stream) {
     const bool wide2 = g.N2 >= g.N1;                 // orientation: the wider side gets the wide tile edge (the 4 wave columns)
     const int narrow = wide2 ? g.N1 : g.N2, wideN = wide2 ? g.N2 : g.N1;
     // tile = (narrow edge, wide edge) with the least padding: 96 / 192 x 384 (ConvNeXt-T widths), 128 / 256 x 256 (ConvNeXt-B widths)
-    static const int cfgs[4][2] = {{96, 384}, {192, 384}, {128, 256}, {256, 256}};
+    // (largest tile first: on equal padding the bigger accumulator tile wins - 384 x 1536 runs on 192 x 384 tiles, not 96 x 384)
+    static const int cfgs[4][2] = {{192, 384}, {256, 256}, {96, 384}, {128, 256}};
     int best = -1;
     double best_waste = 1e9;
     for (int i = 0; i < 4; ++i) {
@@ -356,8 +357,8 @@ bool mmg_tn_wide_launch(GemmTN& g, hipStream_t stream) {
         if (w < best_waste - 1e-9) { best_waste = w; best = i; }
     }
     static const int allow_b = getenv("MMG_TN_WIDE_B") ? atoi(getenv("MMG_TN_WIDE_B")) : 1;     // 0: the 256-wide tiles off (A/B runs)
-    if (!allow_b && best >= 2) {
-        best = narrow <= 96 ? 0 : 1;
+    if (!allow_b && (best == 1 || best == 3)) {      // the 256-wide tiles off: the 384-wide ones or nothing
+        best = narrow <= 96 ? 2 : 0;
         best_waste = (double)(cdiv(narrow, cfgs[best][0]) * cfgs[best][0]) * (cdiv(wideN, 384) * 384) / ((double)narrow * wideN);
     }
     if (best_waste > 1.2) return false;              // badly fitting widths stay on the 128-wide tiles of gemm_bf16.hip
@@ -367,17 +368,17 @@ bool mmg_tn_wide_launch(GemmTN& g, hipStream_t stream) {
     // equal on the stage-1/2 shapes, 2-3 % faster on 1536 x 384; MMG_TN_WIDE_MIRROR=1 brings the mirrored ones back.
     static const int mirror = getenv("MMG_TN_WIDE_MIRROR") ? atoi(getenv("MMG_TN_WIDE_MIRROR")) : 0;
     g.swapped = 0;
-    if (!wide2 && !(mirror && best < 2)) {
+    if (!wide2 && !(mirror && (best == 0 || best == 2))) {
         const bf16_t* t = g.A; g.A = g.B; g.B = t;
         int x = g.N1; g.N1 = g.N2; g.N2 = x;
         x = g.lda; g.lda = g.ldb; g.ldb = x;
         g.swapped = 1;
     }
     if (g.swapped || wide2) {
-        if (best == 0) launch_tw<96, 384>(g, stream);
-        else if (best == 1) launch_tw<192, 384>(g, stream);
-        else if (best == 2) launch_tw<128, 256>(g, stream);
-        else launch_tw<256, 256>(g, stream);
+        if (best == 0) launch_tw<192, 384>(g, stream);
+        else if (best == 1) launch_tw<256, 256>(g, stream);
+        else if (best == 2) launch_tw<96, 384>(g, stream);
+        else launch_tw<128, 256>(g, stream);
     } else {
         if (tn == 96) launch_tw<384, 96>(g, stream); else launch_tw<384, 192>(g, stream);
     }
