@@ -221,7 +221,7 @@ def main():
         model.join_streams()                  # (two-stream mode, MMG_TEXT_STREAM=1: the text tower's backward ran on a side stream)
         sync.finish()
         if optimizer is None:
-            optimizer = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.optimizer.config.learning_rate,
+            optimizer = FusedAdamW(model.parameters(), lr=cfg.optimizer.config.learning_rate,
                                    weight_decay=cfg.optimizer.config.weight_decay)
         optimizer.step()
         return loss

@@ -78,10 +78,11 @@ struct AttArgs {
     int bh0;                            // (sequence, head) index of blockIdx.x = 0 in the mask index (micro-batches of one batch)
 };
 
-// keep / scale of probability (sequence-head bh, query q, key k): see dropout.h
+// keep / scale of probability (sequence-head bh, query q, key k): see dropout.h.  bh goes into the KEY (loop-invariant: one extra
+// hash per workgroup), the 18-bit (q, k) position is the index - no 32-bit wrap however many sequences a batch has.
 __device__ __forceinline__ float att_drop(float v, int bh, int q, int k, const DropArgs d) {
-    const unsigned idx = ((unsigned)bh * 512u + (unsigned)q) * 512u + (unsigned)k;
-    return mmg_drop_bits(idx, d.key) >= d.thresh ? v * d.scale : 0.f;
+    const unsigned idx = (unsigned)q * 512u + (unsigned)k;
+    return mmg_drop_bits(idx, mmg_drop_key_bh(d.key, (unsigned)bh)) >= d.thresh ? v * d.scale : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -9,7 +9,10 @@
 //     keep = fmix32(index * 0x9E3779B1 + key) >= floor(p * 2^32)  (murmur3 finaliser: a bijection of the 32-bit index)
 // Element index (independent of the packed / padded token layout):
 //     hidden sites   : token * C + column,        token = b * S + s of the PADDED batch
-//     attention site : ((b * heads + h) * 512 + query) * 512 + key      (positions inside the sequence; S <= 512)
+//     attention site : query * 512 + key (positions inside the sequence; S <= 512) under the per-(sequence, head) key
+//                      key_bh = fmix32(key + (b * heads + h) * 0xB5297A4D)   - the sequence-head number never enters the 32-bit
+//                      index, so batches of any size draw distinct masks per (b, h) (round 2 indexed ((bh * 512 + q) * 512 + k,
+//                      which wrapped at bh = 16384 = 1366 sequences of 12 heads)
 #pragma once
 #include <stdint.h>
 
@@ -26,6 +29,7 @@ MMG_HD unsigned mmg_fmix32(unsigned x) {
 MMG_HD unsigned mmg_drop_key(unsigned long long seed, unsigned site) {
     return mmg_fmix32((site ^ (unsigned)(seed >> 32)) + (unsigned)seed);
 }
+MMG_HD unsigned mmg_drop_key_bh(unsigned key, unsigned bh) { return mmg_fmix32(key + bh * 0xB5297A4Du); }
 MMG_HD unsigned mmg_drop_bits(unsigned index, unsigned key) { return mmg_fmix32(index * 0x9E3779B1u + key); }
 MMG_HD unsigned mmg_drop_threshold(float p) {
     const double t = (double)p * 4294967296.0;

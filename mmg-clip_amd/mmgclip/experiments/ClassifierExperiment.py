@@ -72,9 +72,11 @@ class ClassifierExperiment:
         lr, wd = self.config.optimizer.config.learning_rate, self.config.optimizer.config.weight_decay
         if _get(config, "optimizer.config.fused", False):
             # the towers' parameter arenas do not exist yet (they are built at the first forward): FusedAdamW finds them from
-            # the parameters at every step
+            # the parameters at every step.  EVERY parameter is listed, frozen ones included, exactly as the reference hands
+            # `model.parameters()` to torch.optim.AdamW (ClassifierExperiment.py:74): the param-group layout of a checkpoint's
+            # optimizer_state_dict is then the same in both directions (frozen parameters never get a gradient and are skipped)
             from ..optim import FusedAdamW
-            self.optimizer = FusedAdamW([p for p in self.model.parameters() if p.requires_grad], lr=lr, weight_decay=wd)
+            self.optimizer = FusedAdamW(self.model.parameters(), lr=lr, weight_decay=wd)
         else:
             self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=wd)
 

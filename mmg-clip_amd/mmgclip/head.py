@@ -123,11 +123,12 @@ def cross_entropy(logits, labels=None, weight=1.0):
 class _HipHeadBackend:
     """The product arithmetic of the fused loss: three entry points of libmmgclip_hip.so.
 
-    (tests/test_distributed_cpu.py swaps in an oracle-backed object with the same three methods to exercise the
-    collective choreography below on CPU/gloo; the product path never does.)"""
+    No product signature selects anything else; tests/test_distributed_cpu.py replaces this module attribute in its own worker
+    processes to exercise the collective choreography below on CPU/gloo."""
 
     @staticmethod
     def rows_forward(x_loc, y_all, scale, diag_off):
+        _hip.require_gpu(x_loc, y_all, scale)
         lse, pos, _ = rows_forward(x_loc, y_all, scale, diag_off)
         return lse, pos
 
@@ -161,10 +162,8 @@ class FusedClipLoss(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, img, txt, scale, comm, backend):
-        be = backend or _HipHeadBackend
-        if backend is None:
-            _hip.require_gpu(img, txt, scale)
+    def forward(ctx, img, txt, scale, comm):
+        be = _HipHeadBackend
         img, txt = _f32c(img), _f32c(txt)
         scale = _f32c(scale.reshape(1))
         n_loc, D = img.shape
@@ -192,12 +191,12 @@ class FusedClipLoss(torch.autograd.Function):
         coef = 1.0 / (2.0 * ctx.N)
         dimg, dscale = ctx.be.rows_backward(img, txt_all, scale, lse_i, lse_t_all, gout, coef, ctx.off, True)
         dtxt, _ = ctx.be.rows_backward(txt, img_all, scale, lse_t, lse_i_all, gout, coef, ctx.off, False)
-        return dimg, dtxt, dscale.reshape(()), None, None
+        return dimg, dtxt, dscale.reshape(()), None
 
 
-def fused_clip_loss(image_embeddings, text_embeddings, logit_scale, comm=None, _backend=None):
+def fused_clip_loss(image_embeddings, text_embeddings, logit_scale, comm=None):
     """CLIPLoss on normalised embeddings; `logit_scale` is the already exponentiated scale (a tensor)."""
-    return FusedClipLoss.apply(image_embeddings, text_embeddings, logit_scale, comm, _backend)
+    return FusedClipLoss.apply(image_embeddings, text_embeddings, logit_scale, comm)
 
 
 def greedy_threshold_labels(sim, threshold):

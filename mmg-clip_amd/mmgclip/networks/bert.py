@@ -197,9 +197,27 @@ class BertTower(nn.Module):
         """which: 1 attention probabilities, 2 attention output dense, 3 FFN output dense."""
         return 4 * layer + which
 
+    def reseed_dropout(self, seed=None):
+        """Restart the tower's private dropout-seed stream from (seed, rank); seed=None: the last `seeding()` call's seed, or
+        torch.initial_seed() when `seeding` never ran.  Called by itself whenever `utils.global_utils.seeding` has run since the
+        last draw, so the reference's `seeding(config.base.seed)` reproduces a run."""
+        from ..utils.global_utils import seed_epoch
+        epoch, base = seed_epoch()
+        if seed is None:
+            seed = base if base is not None else torch.initial_seed()
+        rank = int(os.environ.get("RANK", "0"))
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        # splitmix-style fold of (seed, rank): every data-parallel rank draws its own masks for its own samples
+        mixed = (int(seed) * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & 0x7FFFFFFFFFFFFFFF
+        self._drop_gen = torch.Generator().manual_seed(mixed)
+        self._drop_epoch = epoch
+
     def _draw_dropout(self):
-        """(p_hidden, p_attention, seed) for this forward, or None (eval mode, dropout=False, both p = 0).  The seed comes from
-        torch's CPU generator, so torch.manual_seed makes a run reproducible and ranks seeded differently draw different masks."""
+        """(p_hidden, p_attention, seed) for this forward, or None (eval mode, dropout=False, both p = 0).  The seed comes from a
+        generator the tower owns, derived from (base seed, rank): torch's global CPU generator is never consumed (the reference's
+        nn.Dropout does not touch it either: its draws belong to the DataLoader's sampler), `seeding(s)` reproduces a run, and
+        data-parallel ranks draw different masks."""
         cfg = self.config
         if not (self.training and self.dropout) or (cfg.hidden_dropout_prob == 0.0 and cfg.attention_probs_dropout_prob == 0.0):
             return None
@@ -208,7 +226,10 @@ class BertTower(nn.Module):
         if self.next_dropout_seed is not None:
             seed, self.next_dropout_seed = int(self.next_dropout_seed), None
         else:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            from ..utils.global_utils import seed_epoch
+            if getattr(self, "_drop_gen", None) is None or self._drop_epoch != seed_epoch()[0]:
+                self.reseed_dropout()
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._drop_gen).item())
         return cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob, seed
 
     _warned_long_attention_dropout = False

@@ -11,7 +11,9 @@ arena's flat gradient buffer; otherwise its trainable parameters are updated one
 
 State layout = torch.optim.AdamW's: `state[p] = {'step': fp32 0-d tensor, 'exp_avg', 'exp_avg_sq'}`, so
 `state_dict()` / `load_state_dict()` (what EarlyStopper writes as 'optimizer_state_dict', callbacks/early_stopping.py:52-65)
-round-trip and are interchangeable with the reference's torch.optim.AdamW.  For arena parameters `exp_avg` / `exp_avg_sq` are
+round-trip and are interchangeable with the reference's torch.optim.AdamW PROVIDED both list the same parameters in the same order:
+the reference passes `model.parameters()` - frozen BERT included - and so does ClassifierExperiment here (parameters without a
+gradient are skipped and get no state, as in torch).  For arena parameters `exp_avg` / `exp_avg_sq` are
 views into two flat buffers (rebuilt from the per-parameter tensors after a load)."""
 import torch
 

@@ -35,6 +35,7 @@ class ParamArena:
         self._by_name = dict(named_params)
         self.manual_version = 0
         self.ready_hook = None              # ready_hook(arena, lo, hi): gradients of elements [lo, hi) are final (distributed.GradSync)
+        self.open_backwards = 0             # recorded forwards of the owning tower whose backward has not arrived yet (note_forward)
 
     # ---- views -------------------------------------------------------------------------------------------
     def p(self, name):
@@ -119,23 +120,26 @@ class ParamArena:
 # mmgclip/networks/mmgclip_model.py:154-164) and every run has its own autograd backward accumulating into the same arena.
 # `post_backward_hook(arena)` (the gradient all-reduce of distributed.GradSync) must fire after the LAST of them only.
 def note_forward(tower, needs_grad):
-    """Call from the tower's forward: one more backward will arrive if this forward was recorded for autograd."""
+    """Call from the tower's forward: one more backward will arrive if this forward was recorded for autograd.  The count lives
+    on the tower's arena, so that whoever owns the arena's all-reduce (distributed.GradSync.finish) can reset it at the step's end."""
     if needs_grad:
-        tower._open_backwards = getattr(tower, "_open_backwards", 0) + 1
+        tower._arena.open_backwards += 1
 
 
 def backward_finished(tower):
     """Call at the end of the tower's autograd backward; fires the hook once no recorded forward is left without its backward."""
-    tower._open_backwards = max(0, getattr(tower, "_open_backwards", 0) - 1)
-    if tower._open_backwards == 0 and tower.post_backward_hook is not None:
-        tower.post_backward_hook(tower._arena)
+    a = tower._arena
+    a.open_backwards = max(0, a.open_backwards - 1)
+    if a.open_backwards == 0 and tower.post_backward_hook is not None:
+        tower.post_backward_hook(a)
 
 
 def last_backward(tower):
     """True inside the LAST open backward of the tower for this step: only then are finished layers' gradients final."""
-    return getattr(tower, "_open_backwards", 1) <= 1
+    return tower._arena.open_backwards <= 1
 
 
 def begin_step(tower):
     """Forget forwards whose backward never came (e.g. an evaluation pass run with gradients enabled)."""
-    tower._open_backwards = 0
+    if getattr(tower, "_arena", None) is not None:
+        tower._arena.open_backwards = 0

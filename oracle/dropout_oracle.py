@@ -38,9 +38,10 @@ def drop_threshold(p):
     return 0 if t <= 0 else (4294967295 if t >= 4294967295.0 else int(t))
 
 
-def keep_mask(index, p, seed, site):
-    """Boolean array: element `index` (any integer array, taken modulo 2^32) survives dropout."""
-    key = np.uint64(drop_key(seed, site))
+def keep_mask(index, p, seed, site, key=None):
+    """Boolean array: element `index` (any integer array, taken modulo 2^32) survives dropout (`key`: an array of per-element
+    keys replacing drop_key(seed, site))."""
+    key = np.uint64(drop_key(seed, site)) if key is None else _u32(key)
     bits = fmix32((_u32(index) * np.uint64(0x9E3779B1) + key) & _M32)
     return bits >= np.uint64(drop_threshold(p))
 
@@ -51,12 +52,14 @@ def hidden_mask(n_tokens, C, p, seed, site):
     return keep_mask(idx, p, seed, site)
 
 
-def attention_mask(B, heads, S, p, seed, site):
-    """[B, heads, S(query), S(key)] keep mask of the attention-probability dropout (index = ((bh * 512) + q) * 512 + k)."""
-    bh = np.arange(B * heads, dtype=np.uint64)[:, None, None]
+def attention_mask(B, heads, S, p, seed, site, first_sequence=0):
+    """[B, heads, S(query), S(key)] keep mask of the attention-probability dropout of sequences first_sequence .. first_sequence + B:
+    index = q * 512 + k under the per-(sequence, head) key fmix32(key + bh * 0xB5297A4D), bh = sequence * heads + head."""
+    bh = np.arange(B * heads, dtype=np.uint64)[:, None, None] + np.uint64(first_sequence * heads)
+    key_bh = fmix32((np.uint64(drop_key(seed, site)) + bh * np.uint64(0xB5297A4D)) & _M32)
     q = np.arange(S, dtype=np.uint64)[None, :, None]
     k = np.arange(S, dtype=np.uint64)[None, None, :]
-    return keep_mask((bh * np.uint64(512) + q) * np.uint64(512) + k, p, seed, site).reshape(B, heads, S, S)
+    return keep_mask(q * np.uint64(512) + k + np.uint64(0) * bh, p, seed, site, key=key_bh).reshape(B, heads, S, S)
 
 
 # dropout sites of the text tower (mmg-clip_amd/mmgclip/networks/bert.py)

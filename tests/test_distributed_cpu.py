@@ -1,6 +1,7 @@
 """world_size-2 gloo tests (CPU) of the data-parallel choreography: embedding all-gather, LSE all-gather, locally
-complete gradients, summed parameter gradients.  The device arithmetic is replaced by the CPU oracle through the
-test-only backend hook of FusedClipLoss; everything else (Comm, GradSync, the autograd Function) is the product code."""
+complete gradients, summed parameter gradients.  The device arithmetic (`head._HipHeadBackend`, three C-ABI calls) is replaced by
+the CPU oracle by patching that module attribute inside the test processes; everything else (Comm, GradSync, the autograd
+Function) is the product code."""
 import os
 import socket
 import sys
@@ -62,7 +63,8 @@ def _worker(rank, world, port, golden, q):
     img = (img_all[sl] @ w_img.t())
     txt = txt_all[sl].clone().requires_grad_(True)
     ie, te = O.l2_normalize(img), O.l2_normalize(txt)
-    loss = head.fused_clip_loss(ie, te, ls.exp(), comm, OracleHeadBackend)
+    head._HipHeadBackend = OracleHeadBackend          # this worker process only
+    loss = head.fused_clip_loss(ie, te, ls.exp(), comm)
     loss.backward()
     sync = distributed.GradSync(comm, arenas=(), extra_params=[w_img, ls])
     sync.finish()
@@ -99,7 +101,7 @@ def test_global_batch_loss_and_grad_sync_gloo(golden_dir, world):
         assert r["dw"] < 1e-4 and r["dls"] < 1e-4 and r["dtxt"] < 1e-4, r    # summed grads == unsharded grads
 
 
-def test_comm_none_is_local_batch(golden_dir):
+def test_comm_none_is_local_batch(golden_dir, monkeypatch):
     """comm=None reproduces the reference's local-batch CLIPLoss exactly (P = 1 special case)."""
     for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
         if p not in sys.path:
@@ -107,7 +109,8 @@ def test_comm_none_is_local_batch(golden_dir):
     from mmgclip import head
     g = np.load(os.path.join(golden_dir, "g2_head_n8.npz"))
     ie, te = torch.from_numpy(g["image_embeddings"]), torch.from_numpy(g["text_embeddings"])
-    loss = head.fused_clip_loss(ie, te, torch.from_numpy(g["scale"]), None, OracleHeadBackend)
+    monkeypatch.setattr(head, "_HipHeadBackend", OracleHeadBackend)
+    loss = head.fused_clip_loss(ie, te, torch.from_numpy(g["scale"]), None)
     assert abs(float(loss) - float(g["clip_loss"])) < 2e-6 * abs(float(g["clip_loss"])) + 2e-6
 
 
@@ -139,7 +142,7 @@ class _OracleClipLoss(torch.nn.Module):
 
     def forward(self, image_embeddings, text_embeddings, logit_scale, **kwargs):
         from mmgclip import head
-        loss = head.fused_clip_loss(image_embeddings, text_embeddings, logit_scale, self.comm, OracleHeadBackend)
+        loss = head.fused_clip_loss(image_embeddings, text_embeddings, logit_scale, self.comm)
         return loss, torch.arange(image_embeddings.shape[0])
 
 
@@ -174,7 +177,8 @@ def _experiment_worker(rank, world, port, tmpdir, global_loss, q):
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
-    from mmgclip import distributed
+    from mmgclip import distributed, head
+    head._HipHeadBackend = OracleHeadBackend          # this worker process only
     comm = distributed.init_from_env("gloo")
     exp, losses = _run_experiment(comm, rank, world, tmpdir, global_loss)
     # rank-0-only checkpoint writer
@@ -186,7 +190,7 @@ def _experiment_worker(rank, world, port, tmpdir, global_loss, q):
 
 
 @pytest.mark.parametrize("global_loss", [True, False])
-def test_classifier_experiment_train_syncs_gradients_gloo(tmp_path, global_loss):
+def test_classifier_experiment_train_syncs_gradients_gloo(tmp_path, global_loss, monkeypatch):
     """create_experiment(...).train() on 2 ranks (half a batch each): parameters identical on both ranks after the epochs and
     - with the global-batch loss - equal to the 1-rank run on the whole batches; only rank 0 writes the checkpoint."""
     ctx = mp.get_context("spawn")
@@ -206,6 +210,8 @@ def test_classifier_experiment_train_syncs_gradients_gloo(tmp_path, global_loss)
     for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
+    from mmgclip import head
+    monkeypatch.setattr(head, "_HipHeadBackend", OracleHeadBackend)
     exp, l_ref = _run_experiment(None, 0, 1, str(tmp_path))
     ref = {k: v.detach().numpy() for k, v in exp.model.state_dict().items()}
     moved = max(float(np.abs(ref[k] - v.detach().numpy()).max()) for k, v in _TinyClip().state_dict().items())
@@ -246,6 +252,32 @@ def _bucket_worker(rank, world, port, q):
         sync.finish()
         want = torch.arange(arena.size, dtype=torch.float32) * sum(r + 1 for r in range(world))
         out[name] = dict(err=float((arena.grad - want).abs().max()), log=log, early=issued_before_end)
+    # a recorded forward whose backward never arrives must not leave part of the arena unreduced, nor disable
+    # the hook for the following steps; MMG_GRAD_OVERLAP=0 semantics (one collective per arena after the backward) give the same sums
+    from mmgclip.params import backward_finished, last_backward, note_forward
+
+    class _Tower:
+        post_backward_hook = None
+    tower = _Tower()
+    tower._arena = arena
+    want = torch.arange(arena.size, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    for name, overlap in (("stray_forward", True), ("no_overlap", False)):
+        sync = distributed.GradSync(comm, arenas=[arena], extra_params=[], bucket_bytes=1, overlap=overlap)
+        tower.post_backward_hook = sync.reduce_arena_async
+        steps = []
+        for stray in (True, False):                      # step 1 has one forward too many, step 2 is a normal step
+            arena.grad.copy_(torch.arange(arena.size, dtype=torch.float32) * (rank + 1))
+            note_forward(tower, True)
+            if stray:
+                note_forward(tower, True)                # e.g. an eval pass without no_grad(): its backward never comes
+            if last_backward(tower):                     # (what the towers do: marks only in the last open backward)
+                arena.mark_ready("layer.5.")
+            backward_finished(tower)                     # hook fires only when no forward is left open
+            hooked = len(sync.log)
+            sync.finish()
+            steps.append(dict(err=float((arena.grad - want).abs().max()), hooked=hooked, calls=len(sync.last_log),
+                              covered=sum(hi - lo for _, lo, hi in sync.last_log), open=arena.open_backwards))
+        out[name] = steps
     q.put((rank, out, arena.size, arena.range_of("layer.5."), arena.range_of(("layer.1.", "layer.2."))))
     dist.barrier()
     dist.destroy_process_group()
@@ -268,8 +300,14 @@ def test_bucketed_gradient_allreduce_gloo():
     for rank, out, size, r5, r12 in results:
         L = 10048                                        # 100 * 100 rounded up to 64 elements
         assert size == 6 * L + 64 and r5 == (5 * L, 6 * L) and r12 == (L, 3 * L)
-        for name in out:
+        for name in ("buckets", "no_marks", "partial"):
             assert out[name]["err"] == 0.0, (rank, name, out[name])      # exact: integers < 2^24 summed over 2 ranks... per element once
         assert out["buckets"]["log"] == [(4 * L, 6 * L), (2 * L, 4 * L), (0, 2 * L), (6 * L, size)] and out["buckets"]["early"] == 3
         assert out["no_marks"]["log"] == [(0, size)] and out["no_marks"]["early"] == 0
         assert out["partial"]["log"] == [(5 * L, 6 * L), (3 * L, 4 * L), (0, 3 * L), (4 * L, 5 * L), (6 * L, size)]
+        stray, normal = out["stray_forward"]
+        # the stray forward kept the hook (and the marks) from firing: finish() reduced the whole arena, once, and reset the count
+        assert stray == dict(err=0.0, hooked=0, calls=1, covered=size, open=0), stray
+        assert normal == dict(err=0.0, hooked=3, calls=3, covered=size, open=0), normal      # mark, then the two complements
+        for st in out["no_overlap"]:                     # overlap off: nothing before finish(), one collective per arena
+            assert st == dict(err=0.0, hooked=0, calls=1, covered=size, open=0), st

@@ -109,6 +109,30 @@ def test_attention_dropout_forward_backward_match_torch_with_the_same_mask(dev, 
     assert torch.equal((ctx_1.float() * valid[S:2 * S].to(dev)).cpu(), (ctx.float() * valid.to(dev)).cpu()[S:2 * S])
 
 
+def test_attention_dropout_masks_do_not_repeat_across_large_batches(dev):
+    """round 2's index ((bh * 512 + q) * 512 + k wrapped at bh = 16384, so sequence b and b + 1366 (12 heads) shared their
+    masks.  The sequence-head number now keys the hash: a micro-batch starting at sequence 1366 / 5000 draws the oracle's mask for THOSE
+    sequences, and that mask differs from sequence 0's."""
+    from mmgclip import kernels as K
+    heads, p, seed, site, S, B = 12, 0.1, 77, 9, 32, 2
+    Hd = heads * 64
+    g = torch.Generator().manual_seed(3)
+    qkv = (torch.randn(B * S, 3 * Hd, generator=g) * 0.8).to(torch.bfloat16)
+    mask = torch.ones(B, S, dtype=torch.long)
+    keep0 = D.attention_mask(B, heads, S, p, seed, site)
+    outs = {}
+    for first in (0, 1366, 5000):
+        keep = D.attention_mask(B, heads, S, p, seed, site, first_sequence=first)
+        if first:
+            assert (keep != keep0).mean() > 0.1
+        ref = _attention_reference(qkv.float(), [S] * B, S, heads, torch.from_numpy(keep), p)
+        ctx, _ = K.attention_dropout_fwd(qkv.to(dev), mask.to(dev), B, S, heads, p, seed, site, first_sequence=first)
+        r, c = _rel(ctx, ref)
+        assert r < 2e-2 and c > 0.9995, (first, r, c)
+        outs[first] = ctx.float().cpu()
+    assert _rel(outs[1366], outs[0])[0] > 0.1 and _rel(outs[5000], outs[1366])[0] > 0.1
+
+
 def _tower(dev, layers=3, seed=4):
     from mmgclip.networks.bert import BertConfigLite
     from mmgclip.networks.encoder import BertEncoder
@@ -153,9 +177,11 @@ def test_bert_tower_training_mode_matches_the_oracle_mask_for_mask(dev, packed, 
 
 
 def test_bert_tower_dropout_switches(dev, monkeypatch):
-    """train() draws a fresh seed per forward from torch's generator; eval(), dropout=False and MMG_BERT_DROPOUT=0 give the
-    deterministic tower; torch.manual_seed reproduces a training-mode run; micro-batching does not change the masks."""
+    """train() draws a fresh seed per forward from the tower's own generator (torch's global CPU stream is left alone: ADVICE r2);
+    eval(), dropout=False and MMG_BERT_DROPOUT=0 give the deterministic tower; `seeding(s)` reproduces a training-mode run;
+    another rank draws other masks; micro-batching does not change the masks."""
     from mmgclip.dataset.synthetic import synthetic_tokens
+    from mmgclip.utils.global_utils import seeding
     enc, sd = _tower(dev, layers=2)
     tok = {k: v.to(dev) for k, v in synthetic_tokens(6, 40, 3000, torch.Generator().manual_seed(1)).items()}
     run = lambda: enc.hidden_states(tok).detach().clone()              # noqa: E731
@@ -163,11 +189,17 @@ def test_bert_tower_dropout_switches(dev, monkeypatch):
     e0, e1 = run(), run()
     assert torch.equal(e0, e1)
     enc.train()
-    torch.manual_seed(11)
+    seeding(11)
+    state = torch.get_rng_state()
     t0, t1 = run(), run()
     assert not torch.equal(t0, t1) and not torch.equal(t0, e0)
-    torch.manual_seed(11)
+    assert torch.equal(torch.get_rng_state(), state)                   # the global CPU generator was not consumed
+    seeding(11)
     assert torch.equal(run(), t0)
+    monkeypatch.setenv("RANK", "1")                                    # the same base seed on another data-parallel rank
+    seeding(11)
+    assert not torch.equal(run(), t0)
+    monkeypatch.setenv("RANK", "0")
     enc.next_dropout_seed = 5
     whole = run()
     enc.micro_batch = 4
@@ -199,7 +231,8 @@ def test_whole_model_step_with_dropout_is_the_same_on_one_or_two_streams(dev, mo
         model = MMGCLIP(cfg).train()
         assert model.text_encoder.dropout and model.text_encoder.training
         crit = create_loss("MMGCLIPLoss")()
-        torch.manual_seed(123)                                     # the dropout seeds of the steps below come from this generator
+        from mmgclip.utils.global_utils import seeding
+        seeding(123)                                               # restarts the tower's dropout-seed stream
         losses = []
         for step in range(2):
             batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=9 + step, with_impression=True)

@@ -242,3 +242,28 @@ def test_two_rank_experiment_train_equals_one_rank(dev, tmp_path, loss_name):
     t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}    # noqa: E731
     cos, ratio = _delta_agreement(t(sd0), t(ref), t(w0))
     assert cos > 0.9 and 0.9 < ratio < 1.1, (cos, ratio)          # 4 Adam steps: same movement as the 1-rank run on whole batches
+
+
+def test_fused_adamw_loads_a_reference_style_state_dict_with_frozen_bert(dev, tmp_path):
+    """the reference builds torch.optim.AdamW(model.parameters()) with the frozen BERT listed
+    (/root/reference/mmgclip/experiments/ClassifierExperiment.py:74).  A state dict written that way loads into the fused optimizer
+    of the same model (and the other way round): same param-group sizes, state only for the parameters that trained."""
+    frozen = ["networks.text_encoder.freeze=true", "optimizer.config.learning_rate=1e-3"]
+    ref = _experiment(str(tmp_path / "ref"), frozen + ["optimizer.config.fused=false"], _loader(steps=2))
+    assert type(ref.optimizer).__name__ == "AdamW"
+    ref.scheduler.step()
+    ref.train()
+    sd = ref.optimizer.state_dict()
+    n_all = sum(1 for _ in ref.model.parameters())
+    n_train = sum(1 for p in ref.model.parameters() if p.requires_grad)
+    assert n_train < n_all and len(sd["param_groups"][0]["params"]) == n_all and len(sd["state"]) == n_train
+    fused = _experiment(str(tmp_path / "fused"), frozen + ["optimizer.config.fused=true"], _loader(steps=1))
+    assert type(fused.optimizer).__name__ == "FusedAdamW"
+    assert len(fused.optimizer.state_dict()["param_groups"][0]["params"]) == n_all
+    fused.model.load_state_dict(ref.model.state_dict())
+    fused.optimizer.load_state_dict(sd)                    # raised "size of parameter group" with the filtered list of round 2
+    fused.scheduler.step()
+    fused.train()
+    sd2 = fused.optimizer.state_dict()
+    assert len(sd2["state"]) == n_train and all(float(v["step"]) == 3.0 for v in sd2["state"].values())
+    ref.optimizer.load_state_dict(sd2)                     # and back
