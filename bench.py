@@ -11,10 +11,15 @@ both towers (nothing frozen, nothing skipped).  Inputs are resident in HBM befor
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     : the bf16 MFMA GEMM (gemm_nt_kernel) — algorithmic FLOPs of every launch / its HIP-event duration,
-                 measured in the timed region on the launch stream;
-  cpu_baseline : the CPU oracle (oracle/*, fp32 PyTorch restatement) on BASELINE config C1 (n=8, 224x224, S=77), timed
-                 on this host's cores, rank 0, N=1 only.
+  roofline     : the kernel instantiation with the largest share of a step - algorithmic bytes / FLOPs of every launch over its
+                 HIP-event duration, per shape class.  The K timed steps run UNINSTRUMENTED; the events are recorded in
+                 `--profile-steps` extra steps after the timed region, with both towers on one stream so that no event pair spans
+                 another stream's kernel (mmgclip/profile.py), labelled with the instantiation name rocprofv3 prints;
+  comm         : (N > 1) bytes all-gathered / all-reduced per step, device time of the gradient all-reduces and how long the
+                 compute stream waited for them (mmgclip/distributed.py: GradSync.report);
+  cpu_baseline : the CPU oracle (oracle/*, fp32 PyTorch restatement) on BASELINE config C1 (n=8, 224x224) at S=77 and S=256, the
+                 reference-faithful step at both lengths and a bounded sample of C2 itself, timed on this host's cores, rank 0,
+                 N=1 only.
 """
 import argparse
 import json
@@ -79,8 +84,10 @@ def _host_cores():
 
 def cpu_baseline_worker(seconds_budget):
     """Oracle training step (ConvNeXt-T + BERT-base + projection + CLIPLoss + AdamW, fp32) on the host cores; prints JSON.
-    `value` is BASELINE.md §4's prescription: config C1 (8 pairs of 224x224, S=77), the reference's own CPU-runnable case;
-    a bounded sample of the benchmarked workload itself (C2 shapes: 1024x1024 images, 4 pairs per step) is reported beside it."""
+    `value` is BASELINE.md §4's prescription: config C1 (8 pairs of 224x224, S=77), the reference's own CPU-runnable case; beside it
+    the same step at S=256 (the reference's default tokenizer length), the reference-faithful step (pre-extracted features, frozen
+    BERT forward, two trainable projections) at both lengths, and a bounded sample of the benchmarked workload itself (C2 shapes:
+    1024x1024 images, 4 pairs per step)."""
     from mmgclip.dataset.synthetic import synthetic_batch
     from mmgclip.networks.bert import BertConfigLite, _hf_layout
     from mmgclip.networks.convnext import build_features
@@ -92,46 +99,67 @@ def cpu_baseline_worker(seconds_budget):
     feats, bert = build_features("tiny", 1), _hf_layout(BertConfigLite())
     wi, wt = torch.nn.Linear(768, 512, bias=False), torch.nn.Linear(768, 512, bias=False)
     ls = torch.tensor(2.6593)
-    params = list(feats.parameters()) + [p for n, p in bert.named_parameters() if not n.startswith("pooler.")] + \
-        list(wi.parameters()) + list(wt.parameters())
-    opt = torch.optim.AdamW(params, lr=5e-5, weight_decay=1e-4)
+    heads = list(wi.parameters()) + list(wt.parameters())
+    bert_params = [p for n, p in bert.named_parameters() if not n.startswith("pooler.")]
+    opt_full = torch.optim.AdamW(list(feats.parameters()) + bert_params + heads, lr=5e-5, weight_decay=1e-4)
+    opt_heads = torch.optim.AdamW(heads, lr=5e-5, weight_decay=1e-4)
     csd = {"features." + k: v for k, v in feats.named_parameters()}
     bsd = dict(bert.named_parameters())
 
-    def step(batch):
-        opt.zero_grad(set_to_none=True)
-        pooled, _ = E.convnext_forward(csd, batch["image"])
+    def text_features(batch):
         hid = E.bert_forward(bsd, batch["text_tokens"]["input_ids"], batch["text_tokens"]["attention_mask"],
                              batch["text_tokens"]["token_type_ids"])
-        tf = O.eos_pool(hid, batch["text_tokens"]["attention_mask"])
-        out = O.forward_tail(O.linear_projection(pooled.flatten(1), wi.weight), O.linear_projection(tf, wt.weight), ls)
+        return O.eos_pool(hid, batch["text_tokens"]["attention_mask"])
+
+    def tail(opt, image_features, tf):
+        out = O.forward_tail(O.linear_projection(image_features, wi.weight), O.linear_projection(tf, wt.weight), ls)
         loss, _ = O.clip_loss(out["logits_per_image"], out["logits_per_text"])
         loss.backward()
         opt.step()
         return loss.item()
 
-    def measure(n, image_size, budget, max_steps):
-        batch = synthetic_batch(n, S=77, image_size=image_size, seed=42)
+    def step(batch):                       # the north-star step: both towers trained
+        opt_full.zero_grad(set_to_none=True)
+        pooled, _ = E.convnext_forward(csd, batch["image"])
+        return tail(opt_full, pooled.flatten(1), text_features(batch))
+
+    def step_faithful(batch):              # what the reference's own step computes
+        opt_heads.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            tf = text_features(batch)
+        return tail(opt_heads, torch.flatten(batch["image_features"], 1), tf)
+
+    def measure(fn, n, S, image_size, budget, warm, max_steps):
+        batch = synthetic_batch(n, S=S, image_size=image_size, seed=42)
         times, t_end = [], time.time() + budget
-        while len(times) < 2 or (time.time() < t_end and len(times) < max_steps):      # first step = warm-up
+        while len(times) < warm + 1 or (time.time() < t_end and len(times) < warm + max_steps):
             t0 = time.time()
-            step(batch)
+            fn(batch)
             times.append(time.time() - t0)
-        timed = sorted(times[1:])
-        return timed[len(timed) // 2], len(timed)
+        w = min(warm, len(times) - 1)
+        timed = sorted(times[w:])
+        return timed[len(timed) // 2], len(timed), w
+
+    def leg(fn, n, S, image_size, budget, warm, max_steps, what):
+        med, k, w = measure(fn, n, S, image_size, budget, warm, max_steps)
+        return {"value": round(n / med, 3), "unit": "image-text pairs/sec", "cores": cores, "median_ms_per_step": round(med * 1000, 1),
+                "sample": f"{what}: median of {k} timed step(s) after {w} warm-up"}
 
     n2 = int(os.environ.get("MMG_CPU_SAMPLE_PAIRS", "4"))
-    med1, k1 = measure(8, 224, 0.3 * seconds_budget, 12)
-    med2, k2 = measure(n2, 1024, 0.7 * seconds_budget, 4)
+    b = seconds_budget
+    c1 = leg(step, 8, 77, 224, 0.20 * b, 3, 10, "BASELINE config C1 (BASELINE.md §4): oracle fp32 training step (ConvNeXt-T + BERT-base, "
+             "fwd+bwd+AdamW), n=8, 224x224, S=77")
+    s256 = leg(step, 8, 256, 224, 0.30 * b, 2, 10, "config C1 at the reference's default tokenizer length: n=8, 224x224, S=256")
+    f77 = leg(step_faithful, 8, 77, None, 0.05 * b, 3, 10, "reference-faithful step (pre-extracted 768-d features, frozen BERT-base "
+              "forward, two 768->512 projections trained), n=8, S=77")
+    f256 = leg(step_faithful, 8, 256, None, 0.15 * b, 2, 10, "reference-faithful step, n=8, S=256")
+    c2 = leg(step, n2, 77, 1024, 0.30 * b, 1, 3, f"{n2} pairs of the benchmarked C2 workload (1024x1024 images, S=77)")
     print(json.dumps({
-        "value": round(8 / med1, 3), "unit": "image-text pairs/sec", "cores": cores, "kind": "port",
-        "sample": f"BASELINE config C1, the reference's own CPU-runnable case (BASELINE.md §4): oracle fp32 training step (ConvNeXt-T + "
-                  f"BERT-base, fwd+bwd+AdamW), n=8, 224x224, S=77: median of {k1} step(s) after one warm-up, {med1 * 1000:.0f} ms/step",
-        "c2_sample": {"value": round(n2 / med2, 3), "sample": f"{n2} pairs of the benchmarked C2 workload (1024x1024 images, S=77): median of "
-                                                               f"{k2} step(s) after one warm-up, {med2:.2f} s/step"}}), flush=True)
+        "value": c1["value"], "unit": "image-text pairs/sec", "cores": cores, "kind": "port", "sample": c1["sample"],
+        "median_ms_per_step": c1["median_ms_per_step"], "s256": s256, "faithful": {"s77": f77, "s256": f256}, "c2_sample": c2}), flush=True)
 
 
-def cpu_baseline(seconds_budget=30.0, hard_timeout=240.0):
+def cpu_baseline(seconds_budget=75.0, hard_timeout=300.0):
     """Run the worker in a child process so a slow host can never stall the benchmark line."""
     import subprocess
     try:
@@ -164,6 +192,8 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="ConvNeXt blocks with C >= 512: forward pointwise GEMMs on e4m3 MFMA (config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2,
+                    help="instrumented steps run AFTER the timed region for the roofline leg (one stream, HIP events per launch)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--cpu-baseline-worker", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -212,7 +242,7 @@ def main():
         outputs = model(batch, materialize_logits=False)
         loss, _ = criterion(**outputs)
         if sync is None:                      # arenas exist after the first forward
-            sync = distributed.GradSync(comm, arenas(), extra)
+            sync = distributed.GradSync(comm, arenas(), extra, timing=comm is not None)
             if comm is not None:
                 for tower in (getattr(model, "image_encoder", None), model.text_encoder):
                     if tower is not None:
@@ -235,20 +265,39 @@ def main():
     losses = []
     for _ in range(args.warmup):
         losses.append(step().item())
-    if not args.no_roofline:
-        linalg.PROFILE.enable()
+    if sync is not None and comm is not None:           # counters of the warm-up steps are dropped
+        sync.report()
+        comm.report()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps):                           # the timed region: no kernel instrumentation (N > 1: one event pair per gradient all-reduce, `comm`)
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    linalg.PROFILE.disable()
     losses.append(loss.item())
     if comm is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    comm_block = None
+    if comm is not None and sync is not None:
+        comm_block = {**sync.report(), **{k + "_per_step": v // max(args.steps, 1) for k, v in comm.report().items()},
+                      "bucket_env": {k: os.environ.get(k) for k in ("MMG_GRAD_OVERLAP", "MMG_BUCKET_MB", "MMG_RCCL_MAX_CHANNELS")}}
+
+    # the roofline leg: extra steps, every launch of the hot kernels between two HIP events, both towers on ONE stream
+    profile_ms = None
+    if not args.no_roofline and args.profile_steps > 0:
+        model.text_stream_enabled = False
+        step()                                            # (one un-recorded step on the one-stream schedule)
+        linalg.PROFILE.enable()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.profile_steps):
+            step()
+        barrier()
+        profile_ms = (time.perf_counter() - t1) / args.profile_steps * 1000.0
+        linalg.PROFILE.disable()
+        model.text_stream_enabled = True
 
     ms_per_step = elapsed / args.steps * 1000.0
     pairs = args.batch * world * args.steps
@@ -277,28 +326,39 @@ def main():
                    "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
     }
     if rank == 0:
-        if not args.no_roofline:
-            fams = linalg.PROFILE.families()
+        if not args.no_roofline and args.profile_steps > 0:
+            kernels = linalg.PROFILE.kernels()
             # HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/collect_traffic.sh; the
             # counters cannot be read from inside the process), corrected as MI355X_MICROARCH.md prescribes
             tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")) \
                 if os.path.isdir(os.path.join(ROOT, "profiles")) else []
             default_cmd = (args.batch, args.image_size, args.seq_len, args.micro_batch, args.variant, world, args.checkpoint, args.fp8) == \
                 (256, 1024, 77, 256, "tiny", 1, False, False)
-            traffic = json.load(open(os.path.join(ROOT, "profiles", tfile[-1]))).get("families", {}) if (tfile and default_cmd) else {}
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfile[-1]))) if (tfile and default_cmd) else {}
+            traffic = {**tj.get("families", {}), **tj.get("kernels", {})}
             lines = []
-            for fam, st in fams.items():
-                r = linalg.PROFILE.roofline(fam, st)
-                if fam in traffic:
-                    r["traffic"] = round(traffic[fam]["hbm_bytes_per_launch"])
-                    r["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)"
+            for name, st in kernels.items():
+                r = linalg.PROFILE.roofline(name, st)
+                r["ms_per_step"] = round(st["total_ms"] / args.profile_steps, 3)
+                key = name if name in traffic else r["family"]
+                if key in traffic:
+                    r["traffic"] = round(traffic[key]["hbm_bytes_per_launch"])
+                    r["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)" + ("" if key == name else f", mean over {key}")
                     # the PMC counters cannot be read from inside the process: this figure is STATIC, from the committed rocprofv3
                     # passes of this same command, not measured in this run
                     r["traffic_source"] = "static: profiles/%s (rocprofv3 --pmc passes of this command, tools/collect_traffic.sh)" % tfile[-1]
                 lines.append(r)
             if lines:
-                out["roofline"] = lines[0]                 # the kernel with the largest share of the timed region
+                out["roofline"] = lines[0]                 # the kernel with the largest share of a step
                 out["roofline_other_kernels"] = lines[1:]
+                out["roofline_method"] = {
+                    "profiled_steps": args.profile_steps, "profiled_ms_per_step_one_stream": round(profile_ms, 2),
+                    "instrumented_kernel_ms_per_step": round(sum(r["total_ms"] for r in lines) / args.profile_steps, 2),
+                    "event_overhead_us_subtracted": round(linalg.PROFILE.event_overhead_us, 2),
+                    "note": "HIP events around every launch on its own stream, in extra steps after the timed region with the text tower "
+                            "on the main stream; names are the dispatcher's instantiations as rocprofv3 prints them"}
+        if comm_block is not None:
+            out["comm"] = comm_block
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocations in this repo); nothing is
- *     allocated, freed or retained by the library; no global state besides a thread-local error string;
+ *     allocated, freed or retained by the library; no global state besides a thread-local error string (and the opt-in
+ *     kernel-name note of the diagnostics below);
  *   - `stream` is a hipStream_t passed as void* (PyTorch's current stream); every call is asynchronous on it
  *     and safe to capture into a hipGraph;
  *   - matrices are row-major; `ld*` are leading dimensions in ELEMENTS;
@@ -33,6 +34,12 @@ int mmg_abi_version(void);
 const char* mmg_last_error(void);
 const char* mmg_target_arch(void);
 int mmg_device_cu_count(void);
+/* Diagnostics for the measurement leg (bench.py `roofline`, mmgclip/profile.py): while notes are on, every dispatcher records the
+ * name of the kernel instantiation it launches - spelled as rocprofv3's kernel trace spells it, e.g.
+ * "gemm_nt_kernel<256, 256, 64, 4, 2, 0>" - and mmg_last_kernel() returns the calling thread's last one ("" when none).  No
+ * reference counterpart: the reference has no kernels of its own to name. */
+int mmg_set_kernel_notes(int on);
+const char* mmg_last_kernel(void);
 
 /* ---- contrastive head (fp32, f32-input MFMA) ------------------------------------------------------------ */
 

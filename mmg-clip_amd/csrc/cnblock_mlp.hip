@@ -616,6 +616,7 @@ static int launch_mlp_bwd(MlpBwd p, hipStream_t stream) {
     p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     const int cap = Cfg::WGS_BWD * mlp_cu_count();
     const int grid = p.ntiles < cap ? p.ntiles : cap;
+    MMG_NOTE_KERNEL("cnblock_mlp_bwd_kernel<%d, %s, %s>", C, RECOMP ? "true" : "false", p.ln_dw ? "true" : "false");
     if (p.ln_dw) {
         mmg_allow_lds(cnblock_mlp_bwd_kernel<C, RECOMP, true>, lds);
         hipLaunchKernelGGL((cnblock_mlp_bwd_kernel<C, RECOMP, true>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);
@@ -635,6 +636,7 @@ static int launch_mlp_fwd(MlpFwd p, hipStream_t stream) {
     p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     const int cap = Cfg::WGS * mlp_cu_count();
     const int grid = p.ntiles < cap ? p.ntiles : cap;
+    MMG_NOTE_KERNEL("cnblock_mlp_fwd_kernel<%d, %s>", C, p.hpre ? "true" : "false");
     if (p.hpre) {
         mmg_allow_lds(cnblock_mlp_fwd_kernel<C, true>, lds);
         hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, true>), dim3(grid), dim3(Cfg::THREADS), lds, stream, p);

@@ -20,6 +20,10 @@ typedef unsigned short bf16_t;  // raw bf16 bits
 
 // ---- host-side error plumbing (C ABI: int return + mmg_last_error()) ----
 void mmg_set_error(const char* fmt, ...);
+// diagnostics (core.hip): the dispatchers record the name of the kernel instantiation they launch while notes are on
+int mmg_kernel_notes_on(void);
+void mmg_note_kernel(const char* fmt, ...);
+#define MMG_NOTE_KERNEL(...) do { if (mmg_kernel_notes_on()) mmg_note_kernel(__VA_ARGS__); } while (0)
 #define MMG_CHECK_ARG(cond, ...)                 \
     do {                                         \
         if (!(cond)) {                           \

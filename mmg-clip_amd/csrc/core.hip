@@ -11,7 +11,21 @@ void mmg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-MMG_API int mmg_abi_version(void) { return 2; }
+// ---- which kernel did the last entry point launch? (diagnostics: bench.py's roofline leg labels its HIP-event timings with the
+// instantiation a dispatcher chose, so they can be set beside the rocprofv3 kernel trace name for name) ----
+static thread_local char g_kernel[128] = "";
+static int g_notes_on = 0;
+int mmg_kernel_notes_on(void) { return g_notes_on; }
+void mmg_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+MMG_API int mmg_set_kernel_notes(int on) { g_notes_on = on != 0; g_kernel[0] = 0; return 0; }
+MMG_API const char* mmg_last_kernel(void) { return g_kernel; }
+
+MMG_API int mmg_abi_version(void) { return 3; }
 MMG_API const char* mmg_last_error(void) { return g_err; }
 MMG_API const char* mmg_target_arch(void) { return "gfx950"; }
 

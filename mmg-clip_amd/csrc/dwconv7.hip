@@ -483,12 +483,14 @@ MMG_API int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, c
             hipLaunchKernelGGL((dwconv7_rows2_kernel<FL, T>), grid2, dim3(256), shm2, stream, (const bf16_t*)x, w, bias, \
                                (const bf16_t*)add, (bf16_t*)y, H, W, C, tiles_w, nt);                              \
         } while (0)
+        MMG_NOTE_KERNEL("dwconv7_rows2_kernel<%s, %d>", flip ? "true" : "false", TH);
         if (flip) { if (th16) DW_LAUNCH2(true, 16); else DW_LAUNCH2(true, 8); }
         else      { if (th16) DW_LAUNCH2(false, 16); else DW_LAUNCH2(false, 8); }
 #undef DW_LAUNCH2
         MMG_LAUNCH_CHECK("mmg_dwconv7_nhwc");
         return 0;
     }
+    MMG_NOTE_KERNEL("dwconv7_kernel<%s>", flip ? "true" : "false");
     if (flip) {
         mmg_allow_lds(dwconv7_kernel<true>, shm);
         hipLaunchKernelGGL(dwconv7_kernel<true>, grid, dim3(256), shm, stream, (const bf16_t*)x, w, bias, (const bf16_t*)add,
@@ -525,6 +527,7 @@ MMG_API int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* d
     if (per_slab > n * tiles) per_slab = n * tiles;
     if (rows2) {
         const size_t shm2 = (size_t)(TH + 6) * DW_ROWD2 * 4 + 4 * 50 * DW_CB * 4;
+        MMG_NOTE_KERNEL("dwconv7_wgrad_rows2_kernel<%d>", TH);
         if (TH == 16) {
             mmg_allow_lds(dwconv7_wgrad_rows2_kernel<16>, shm2);
             hipLaunchKernelGGL(dwconv7_wgrad_rows2_kernel<16>, dim3(per_slab, slabs), dim3(256), shm2, stream, (const bf16_t*)x,
@@ -537,6 +540,7 @@ MMG_API int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* d
         MMG_LAUNCH_CHECK("mmg_dwconv7_wgrad");
         return 0;
     }
+    MMG_NOTE_KERNEL("dwconv7_wgrad_kernel");
     mmg_allow_lds(dwconv7_wgrad_kernel, shm);
     hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3(per_slab, slabs), dim3(256), shm, stream, (const bf16_t*)x,
                        (const bf16_t*)dy, dw, dbias, n, H, W, C, tiles_w, tiles);

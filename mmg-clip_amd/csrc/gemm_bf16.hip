@@ -387,6 +387,7 @@ static void launch_nt(GemmNT& g, hipStream_t stream) {
     const size_t cs = (size_t)64 * (BN + 4) * 4;
     const size_t shm = stage > cs ? stage : cs;
     mmg_allow_lds(gemm_nt_kernel<BM, BN, BK, WAVES_M, NST, F8>, shm);
+    MMG_NOTE_KERNEL("gemm_nt_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, BK, WAVES_M, NST, F8);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WAVES_M, NST, F8>), dim3(g.tiles_m * g.tiles_n), dim3(WAVES_M * 128), shm,
                        stream, g);
 }
@@ -687,6 +688,7 @@ static void launch_tn(GemmTN& g, hipStream_t stream) {
     const size_t cs = (size_t)64 * (K2 * TN_T + 4) * 4;
     const size_t shm = stage > cs ? stage : cs;
     mmg_allow_lds(gemm_tn_kernel<K1, K2, BK>, shm);
+    MMG_NOTE_KERNEL("gemm_tn_kernel<%d, %d, %d>", K1, K2, BK);
     if (g.xcd_order) {
         const int G = g.xcd_order == 1 ? g.tiles1 : g.tiles2, ngroups = (tiles / G) * chunks;
         hipLaunchKernelGGL((gemm_tn_kernel<K1, K2, BK>), dim3(8 * ((ngroups + 7) / 8) * G), dim3(GEMM_THREADS), shm, stream, g);

@@ -337,6 +337,7 @@ static void launch_tw(GemmTN& g, hipStream_t stream) {
     const size_t cs = (size_t)Cfg::FM * 16 * (T2 + 4) * 4;
     const size_t shm = ring > cs ? ring : cs;
     mmg_allow_lds(gemm_tn_wide_kernel<T1, T2>, shm);
+    MMG_NOTE_KERNEL("gemm_tn_wide_kernel<%d, %d>", T1, T2);
     hipLaunchKernelGGL((gemm_tn_wide_kernel<T1, T2>), dim3(8 * cpx * ntile), dim3(TW_THREADS), shm, stream, g);
 }
 

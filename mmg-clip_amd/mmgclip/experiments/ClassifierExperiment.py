@@ -214,6 +214,13 @@ class ClassifierExperiment:
         return (epoch_loss, aucs.get("malig", -1), aucs.get("shapes", -1), aucs.get("birads", -1),
                 mean_auc if len(metric_names) > 1 else -1)
 
+    def test(self):
+        """Test cycle on the test loader (ClassifierExperiment.py:291-301): `Evaluator(...).evaluate_experiment()`."""
+        from ..evaluator import Evaluator
+        logger.info("Running testing evaluator script.")
+        return Evaluator(config=self.config, test_dataloader=self.test_dataloader, tokenizer=self.tokenizer,
+                         model=self.model).evaluate_experiment()
+
     def run(self):
         self._time_start = time.time()
         for self.current_epoch in range(self.config.scheduler.config.epochs):
@@ -233,5 +240,8 @@ class ClassifierExperiment:
             if self.early_stopper.early_stop:
                 logger.info("Early stopping")
                 break
+        # the end-of-run test pass (ClassifierExperiment.py:337-339); rank 0 alone writes the result files
+        if len(_get(self.config, "dataset.eval.enum_classes", [])) > 0 and self.test_dataloader is not None and self._lead:
+            self.test_results = self.test()
         self._time_end = time.time()
         logger.info(f"Run complete. Total time: {time.strftime('%H:%M:%S', time.gmtime(self._time_end - self._time_start))}")

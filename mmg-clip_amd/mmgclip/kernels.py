@@ -25,8 +25,9 @@ def layernorm_fwd(x, gamma, beta, eps, patch_hw=None, want_stats=True):
         patch = 1
     mean = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
-    call("mmg_layernorm_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), float(eps), ptr(y), y.stride(0), ptr(mean),
-         ptr(rstd), M, C, patch, H, W, stream())
+    PROFILE.timed("layernorm_fwd_kernel", 8.0 * M * C, 4 * M * C,
+                  lambda: call("mmg_layernorm_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), float(eps), ptr(y), y.stride(0), ptr(mean),
+                               ptr(rstd), M, C, patch, H, W, stream()), f"M={M} C={C}" + (" patchified" if patch else ""))
     return y, mean, rstd
 
 
@@ -81,8 +82,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, patch_hw=No
     M, C = x.shape
     dx = out if out is not None else torch.empty(M, C, device=x.device, dtype=BF16)
     patch, H, W = (0, 0, 0) if patch_hw is None else (1, patch_hw[0], patch_hw[1])
-    call("mmg_layernorm_bwd", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
-         dx.stride(0), ptr(dgamma), ptr(dbeta), M, C, patch, H, W, ptr(add), add.stride(0) if add is not None else 0, stream())
+    PROFILE.timed("layernorm_bwd_kernel", 16.0 * M * C, (8 if add is not None else 6) * M * C,
+                  lambda: call("mmg_layernorm_bwd", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+                               dx.stride(0), ptr(dgamma), ptr(dbeta), M, C, patch, H, W, ptr(add), add.stride(0) if add is not None else 0,
+                               stream()), f"M={M} C={C}" + (" patchified" if patch else "") + (" +add" if add is not None else ""))
     return dx
 
 
@@ -141,7 +144,8 @@ def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None, mfma=False
     px = n * H * W * C
     fam = "dwconv7_mfma_kernel" if mfma else ("dwconv7_rows2_kernel" if os.environ.get("MMG_DWCONV_ROWS2", "1") != "0" else "dwconv7_kernel")
     PROFILE.timed(fam, 98.0 * px, (6 if add is not None else 4) * px,
-                  lambda: call("mmg_dwconv7_nhwc_mfma" if mfma else "mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()))
+                  lambda: call("mmg_dwconv7_nhwc_mfma" if mfma else "mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()),
+                  f"n={n} {H}x{W} C={C}" + (" +add" if add is not None else ""))
     return y
 
 
@@ -149,7 +153,7 @@ def dwconv7_wgrad(x, dy, dw49, dbias, n, H, W, C):
     px = n * H * W * C
     fam = "dwconv7_wgrad_rows2_kernel" if os.environ.get("MMG_DWCONV_ROWS2", "1") != "0" else "dwconv7_wgrad_kernel"
     PROFILE.timed(fam, 98.0 * px, 4 * px,
-                  lambda: call("mmg_dwconv7_wgrad", ptr(x), ptr(dy), ptr(dw49), ptr(dbias), n, H, W, C, stream()))
+                  lambda: call("mmg_dwconv7_wgrad", ptr(x), ptr(dy), ptr(dw49), ptr(dbias), n, H, W, C, stream()), f"n={n} {H}x{W} C={C}")
 
 
 def cnblock_supported(C):
@@ -179,7 +183,8 @@ def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_h
     rstd = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
     PROFILE.timed("cnblock_mlp_fwd_kernel", 16.0 * M * C * C, (6 + (8 if want_hpre else 0) + (2 if xln is not None else 0)) * M * C + 16 * C * C,
                   lambda: call("mmg_cnblock_mlp_fwd", ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed), ptr(b1), ptr(b2),
-                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(xln), ptr(mean), ptr(rstd), M, C, stream()))
+                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(xln), ptr(mean), ptr(rstd), M, C, stream()),
+                  f"M={M} C={C}" + (" +hpre" if want_hpre else "") + (" +xln" if xln is not None else ""))
     return (y, hpre, mean, rstd, xln) if want_xln else (y, hpre, mean, rstd)
 
 
@@ -202,7 +207,8 @@ def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None, ln_grads
     PROFILE.timed("cnblock_mlp_bwd_kernel", 16.0 * M * C * C, (24 + (8 if hpre is not None else 0)) * M * C + 24 * C * C,
                   lambda: call("mmg_cnblock_mlp_bwd", ptr(dy), ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed_bwd), ptr(b1),
                                ptr(hpre), ptr(dh), ptr(g), ptr(xln), ptr(dxln), ptr(mean), ptr(rstd),
-                               ptr(ln_grads[0]) if ln_grads else None, ptr(ln_grads[1]) if ln_grads else None, M, C, stream()))
+                               ptr(ln_grads[0]) if ln_grads else None, ptr(ln_grads[1]) if ln_grads else None, M, C, stream()),
+                  f"M={M} C={C}")
     return dh, g, xln, dxln, mean, rstd
 
 

@@ -67,6 +67,13 @@ from .profile import PROFILE  # noqa: E402  (bench.py reads linalg.PROFILE)
 
 _gemm_nt_raw = gemm_nt
 _gemm_tn_raw = gemm_tn_acc
+_EPI_NAMES = {EPI_NONE: "none", EPI_GELU: "gelu", EPI_DGELU: "dgelu", EPI_RELU: "relu", EPI_DRELU: "drelu"}
+
+
+def _nt_label(M, N, K, kw):
+    tags = [_EPI_NAMES.get(kw.get("epi", EPI_NONE), "?")]
+    tags += [t for t, k in (("aux", "aux_out"), ("res", "residual"), ("bias", "bias")) if kw.get(k) is not None]
+    return f"M={M} N={N} K={K} epi={'+'.join(tags)}"
 
 
 def gemm_nt(a, b, out=None, **kw):       # noqa: F811  (profiling shim around the launch)
@@ -79,7 +86,7 @@ def gemm_nt(a, b, out=None, **kw):       # noqa: F811  (profiling shim around th
     for extra in ("residual", "aux_in", "aux_out"):
         if kw.get(extra) is not None:
             nbytes += 2 * M * N
-    return PROFILE.timed("gemm_nt_kernel", 2.0 * M * N * K, nbytes, lambda: _gemm_nt_raw(a, b, out=out, **kw))
+    return PROFILE.timed("gemm_nt_kernel", 2.0 * M * N * K, nbytes, lambda: _gemm_nt_raw(a, b, out=out, **kw), _nt_label(M, N, K, kw))
 
 
 _gemm_nt_fp8_raw = gemm_nt_fp8
@@ -92,7 +99,8 @@ def gemm_nt_fp8(a, b, out=None, **kw):       # noqa: F811
     N = b.shape[0]
     esz = (2, 4, 1)[kw.get("out_kind", OUT_BF16)]
     nbytes = (M * K + N * K) + esz * M * N + sum(2 * M * N for extra in ("residual", "aux_out") if kw.get(extra) is not None)
-    return PROFILE.timed("gemm_nt_fp8_kernel", 2.0 * M * N * K, nbytes, lambda: _gemm_nt_fp8_raw(a, b, out=out, **kw))
+    return PROFILE.timed("gemm_nt_fp8_kernel", 2.0 * M * N * K, nbytes, lambda: _gemm_nt_fp8_raw(a, b, out=out, **kw),
+                         "e4m3 " + _nt_label(M, N, K, kw))
 
 
 def gemm_tn_acc(a, b, out, alpha=1.0, colsum=None):       # noqa: F811
@@ -101,4 +109,4 @@ def gemm_tn_acc(a, b, out, alpha=1.0, colsum=None):       # noqa: F811
     M, N1 = a.shape
     N2 = b.shape[1]
     return PROFILE.timed("gemm_tn_kernel", 2.0 * M * N1 * N2, 2 * M * (N1 + N2) + 4 * N1 * N2,
-                         lambda: _gemm_tn_raw(a, b, out, alpha, colsum))
+                         lambda: _gemm_tn_raw(a, b, out, alpha, colsum), f"M={M} N1={N1} N2={N2}")

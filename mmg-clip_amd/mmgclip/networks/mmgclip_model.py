@@ -135,7 +135,11 @@ class MMGCLIP(nn.Module):
     # current one, and autograd replays each backward on the stream of its forward, so both directions overlap (same-run A/B at C2:
     # 332.4 -> 327.5 ms/step).  Cross-stream tensors are registered with the allocator (record_stream); join_streams() makes the
     # current stream wait for the side stream (call it after backward, before optimizer.step()).
+    text_stream_enabled = True      # set False on an instance to run both towers on the caller's stream (bench.py's profiled steps)
+
     def _text_stream(self):
+        if not self.text_stream_enabled:
+            return None
         on = os.environ.get("MMG_TEXT_STREAM")
         on = (on == "1") if on is not None else bool(_get(self.config.networks, "text_stream", True))
         if not on or not torch.cuda.is_available() or self.config.networks.image_encoder.name not in PIXEL_ENCODERS:

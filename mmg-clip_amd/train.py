@@ -37,7 +37,10 @@ def build_loaders(cfg, rank=0):
     bt, bv = cfg.dataloader.train.batch_size, cfg.dataloader.valid.batch_size
     train = SyntheticLoader(max(1, n_train // bt), bt, seed=cfg.base.seed + 1000 * rank, **kw)
     valid = SyntheticLoader(max(1, n_val // bv), bv, seed=cfg.base.seed + 500000 + 1000 * rank, **kw)
-    return train, valid
+    # the held-out half of the non-training samples (the reference's test split, dataset.py: test_split_ratio); only rank 0 scores it
+    btst = cfg.dataloader.test.batch_size
+    test = SyntheticLoader(max(1, (n - n_train - n_val) // btst), btst, seed=cfg.base.seed + 900000, **{**kw, "with_impression": False})
+    return train, valid, test
 
 
 def main(argv=None):
@@ -49,11 +52,12 @@ def main(argv=None):
     cfg = compose(args.config_path, args.config_name, args.overrides)
     seeding(cfg.base.seed)
     comm = distributed.init_from_env()
-    train_loader, val_loader = build_loaders(cfg, comm.rank if comm else 0)
-    logger.info(f"train batches: {len(train_loader)}, valid batches: {len(val_loader)}")
+    train_loader, val_loader, test_loader = build_loaders(cfg, comm.rank if comm else 0)
+    logger.info(f"train batches: {len(train_loader)}, valid batches: {len(val_loader)}, test batches: {len(test_loader)}")
     experiment = create_experiment(cfg.experiments.config.experiment_name)(
-        config=cfg, train_dataloader=train_loader, valid_dataloader=val_loader, test_dataloader=None, tokenizer=None, comm=comm)
+        config=cfg, train_dataloader=train_loader, valid_dataloader=val_loader, test_dataloader=test_loader, tokenizer=None, comm=comm)
     experiment.run()
+    return experiment
 
 
 if __name__ == "__main__":

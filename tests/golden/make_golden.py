@@ -155,6 +155,31 @@ def golden_head(losses):
         torch.Tensor.cuda = orig_cuda
 
 
+def golden_head_c3(losses):
+    """G2 (config C3: `train_prompt_clf`, 2 ranks x 256 pairs = global batch 512, D = 512): the reference's CLIPLoss
+    (mmgclip/loss/losses.py:28-44) on the UNSHARDED 512 x 512 problem - what the two ranks' sharded arithmetic must reproduce.
+    Lean fixture: inputs, loss and the three gradients only (the embeddings / logits follow from the inputs)."""
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        n, D = 512, 512
+        g = torch.Generator().manual_seed(100 + n)
+        base = torch.randn(1, D, generator=g)
+        img = (0.5 * base + torch.randn(n, D, generator=g)).requires_grad_(True)
+        txt = (0.5 * base + 0.7 * img.detach() + torch.randn(n, D, generator=g)).requires_grad_(True)
+        ls = torch.tensor(float(np.log(1 / 0.07)), requires_grad=True)
+        ie, te, s, li, lt = reference_forward_tail(img, txt, ls)
+        loss, labels = losses.CLIPLoss()(logits_per_image=li, logits_per_text=lt, image_embeddings=ie, text_embeddings=te,
+                                         logit_scale=s)
+        loss.backward()
+        assert labels.tolist() == list(range(n))
+        np.savez_compressed(os.path.join(OUT, "g2_head_n512.npz"), img=t2n(img), txt=t2n(txt), logit_scale_param=t2n(ls),
+                            scale=t2n(s), clip_loss=t2n(loss), clip_dimg=t2n(img.grad), clip_dtxt=t2n(txt.grad),
+                            clip_dlogit_scale=t2n(ls.grad))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+
+
 # literal inputs printed in notebooks/loss.ipynb (cells 11, 13, 15, 17, 18)
 NOTEBOOK_LOGITS = [
     [-0.3695, -0.8987, -0.3323, -0.3540, -0.3375, -0.5998, -0.3583, -0.0797],
@@ -260,8 +285,12 @@ def main():
     losses = load_by_path("ref_losses", "mmgclip/loss/losses.py")
     sched = load_by_path("ref_warmup_cosine", "mmgclip/scheduler/warmup_cosine.py")
     es_mod = load_by_path("ref_early_stopping", "mmgclip/callbacks/early_stopping.py")
+    if "--only-c3" in sys.argv:           # round 3: add the C3 fixture without re-writing the others
+        golden_head_c3(losses)
+        return
     golden_projection(proj)
     golden_head(losses)
+    golden_head_c3(losses)
     golden_averaged(losses)
     golden_schedule(sched)
     golden_early_stopper(es_mod)

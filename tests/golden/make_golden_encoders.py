@@ -224,7 +224,7 @@ def golden_bert(seed=51):
 
 
 # ---- G9: BASELINE config C1, end to end ---------------------------------------------------------------------------------
-def golden_c1(proj_mod, losses_mod, S, seed=61):
+def golden_c1(proj_mod, losses_mod, S, seed=61, min_len=None, tag=""):
     from mmgclip.networks import convnext as CN
     from mmgclip.networks.bert import BertConfigLite, _hf_layout
     n, size = 8, 224
@@ -243,7 +243,7 @@ def golden_c1(proj_mod, losses_mod, S, seed=61):
         pi.layer.weight.copy_(R.seeded_tensor("image_projection_layer.layer.weight", (512, 768), seed + 2))
         pt.layer.weight.copy_(R.seeded_tensor("text_projection_layer.layer.weight", (512, 768), seed + 2))
     img = R.structured_images(n, size, seed)
-    ids, mask, tt = R.ragged_tokens(n, S, seed)
+    ids, mask, tt = R.ragged_tokens(n, S, seed, min_len=min_len)
     ls = torch.tensor(float(np.log(1 / 0.07)), requires_grad=True)
 
     pooled = cnx(pixel_values=scale16(img)).last_hidden_state.mean((2, 3))                 # encoder.py:53-54
@@ -265,7 +265,7 @@ def golden_c1(proj_mod, losses_mod, S, seed=61):
     loss.backward()
 
     inv = {hfk: tvk for tvk, hfk in _convnext_key_pairs(depths)}
-    out = dict(seed=seed, S=S, image_sum=float(img.double().sum()), ids=t2n(ids), mask=t2n(mask),
+    out = dict(seed=seed, S=S, min_len=-1 if min_len is None else int(min_len), image_sum=float(img.double().sum()), ids=t2n(ids), mask=t2n(mask),
                pooled=t2n(pooled), text_features=t2n(tf), image_embeddings=t2n(ie), text_embeddings=t2n(te),
                logits_per_image=t2n(li), logits_per_text=t2n(lt), loss=t2n(loss), labels=t2n(labels),
                d_pooled=t2n(pooled.grad), d_text_features=t2n(tf.grad), d_logit_scale=t2n(ls.grad),
@@ -279,7 +279,7 @@ def golden_c1(proj_mod, losses_mod, S, seed=61):
     used = torch.unique(ids[:, :8])[:24]                                    # some word-embedding rows (also [CLS]/[SEP]/pad)
     out["word_rows"] = t2n(used)
     out["grad.text.embeddings.word_embeddings.weight.rows"] = t2n(bert.embeddings.word_embeddings.weight.grad[used])
-    np.savez_compressed(os.path.join(HERE, f"g9_c1_step_s{S}.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, f"g9_c1_step_s{S}{tag}.npz"), **out)
 
 
 def main(proj_mod=None, losses_mod=None):
@@ -289,9 +289,14 @@ def main(proj_mod=None, losses_mod=None):
     golden_vit()
     golden_resnet()
     golden_bert()
+    if proj_mod is not None and "--only-c1b" in sys.argv:     # round 3: the second C1 batch alone, the other fixtures untouched
+        golden_c1(proj_mod, losses_mod, 256, seed=71, min_len=128, tag="_seed71_long")
+        return
     if proj_mod is not None:
         golden_c1(proj_mod, losses_mod, 77)
         golden_c1(proj_mod, losses_mod, 256)
+        # a second batch (other weights, other images, long prompts only: 128..256 tokens): is the 1e-3 loss bar typical or lucky?
+        golden_c1(proj_mod, losses_mod, 256, seed=71, min_len=128, tag="_seed71_long")
     print("encoder golden vectors written to", HERE)
 
 

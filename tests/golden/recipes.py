@@ -70,12 +70,13 @@ def structured_images(n, size, seed, in_chans=1):
     return torch.from_numpy(out)
 
 
-def ragged_tokens(n, S, seed, vocab_size=28996):
+def ragged_tokens(n, S, seed, vocab_size=28996, min_len=None):
     """input_ids / attention_mask / token_type_ids int64 [n,S] with the reference's collate layout
     (mmgclip/dataset/dataset.py:347: padding='max_length'): [CLS]=101 ... [SEP]=102, pad 0, lengths spread over 8..S."""
     r = _rng(seed, f"tokens{n}x{S}")
-    lens = r.integers(min(8, S), S + 1, n)
-    lens[0], lens[-1] = S, min(8, S)                 # always cover the full-length and the shortest case
+    lo = min(8, S) if min_len is None else int(min_len)           # min_len: long prompts only (the second C1 batch, round 3)
+    lens = r.integers(lo, S + 1, n)
+    lens[0], lens[-1] = S, lo                        # always cover the full-length and the shortest case
     ids = r.integers(1000, vocab_size, (n, S))
     mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int64)
     ids = ids * mask

@@ -55,7 +55,8 @@ def build_c1_model(g, extra=()):
         if a is not None:
             a.touch()
     img = R.structured_images(8, 224, seed)
-    ids, mask, tt = R.ragged_tokens(8, S, seed)
+    min_len = int(g["min_len"]) if "min_len" in g.files and int(g["min_len"]) >= 0 else None
+    ids, mask, tt = R.ragged_tokens(8, S, seed, min_len=min_len)
     assert (ids.numpy() == g["ids"]).all() and abs(float(img.double().sum()) - float(g["image_sum"])) < 1e-6 * float(g["image_sum"])
     batch = {"image": img, "text_tokens": TokenBatch(input_ids=ids, token_type_ids=tt, attention_mask=mask)}
     return model, batch
@@ -116,8 +117,10 @@ def c1_errors(model, batch, g):
     return e
 
 
-@pytest.mark.parametrize("S", [77, 256])
+@pytest.mark.parametrize("S", [77, 256, "256_seed71_long"])
 def test_c1_training_step_matches_golden(dev, golden_dir, S):
+    """S = 77 / 256: the round-1 batch; "256_seed71_long": a second batch - other recipe weights, other images, prompts of 128..256
+    tokens only (VERDICT r2 weak #10: does the 1e-3 loss bar hold beyond one sample?)."""
     g = np.load(os.path.join(golden_dir, f"g9_c1_step_s{S}.npz"))
     model, batch = build_c1_model(g)
     e = c1_errors(model, batch, g)

@@ -16,7 +16,7 @@ OVERRIDES = ["networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_
              "networks.image_encoder.micro_batch=4", "networks.image_encoder.image_size=64"]
 
 
-def _build_and_step(comm, batch):
+def _build_and_step(comm, batch, cfg_name="train_binary_class_clf", overrides=OVERRIDES, overlap=None, want_report=False):
     from mmgclip import distributed
     from mmgclip.config import compose
     from mmgclip.loss.loss_controller import create_loss
@@ -31,18 +31,19 @@ def _build_and_step(comm, batch):
     bert.BertConfigLite.__init__ = small
     try:
         torch.manual_seed(0)
-        model = MMGCLIP(compose(CFG_DIR, "train_binary_class_clf", OVERRIDES)).train()
+        cfg = compose(CFG_DIR, cfg_name, overrides)
+        model = MMGCLIP(cfg).train()
     finally:
         bert.BertConfigLite.__init__ = orig
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.endswith("layer_scale"):
                 p.fill_(0.5)
-    crit = create_loss("CLIPLoss")(comm=comm)
+    crit = create_loss(cfg.loss.config.loss_name)(comm=comm)
     out = model(batch, materialize_logits=False)
     loss, _ = crit(**out)
     extra = [p for n, p in model.named_parameters() if not (n.startswith("image_encoder.") or n.startswith("text_encoder."))]
-    sync = distributed.GradSync(comm, [model.image_encoder.arena, model.text_encoder.arena], extra)
+    sync = distributed.GradSync(comm, [model.image_encoder.arena, model.text_encoder.arena], extra, overlap=overlap, timing=want_report)
     if comm is not None:
         model.image_encoder.post_backward_hook = sync.reduce_arena_async
         model.text_encoder.post_backward_hook = sync.reduce_arena_async
@@ -52,6 +53,10 @@ def _build_and_step(comm, batch):
     g_img = model.image_encoder.arena.grad.clone()
     g_txt = model.text_encoder.arena.grad.clone()
     g_proj = model.image_projection_layer.layer.weight.grad.clone()
+    if want_report:
+        return loss.item(), g_img.cpu(), g_txt.cpu(), g_proj.cpu(), {"sync": sync.report(), "comm": comm.report() if comm else None,
+                                                                     "cfg": {"loss": cfg.loss.config.loss_name, "dropout": cfg.networks.dropout.config.dropout,
+                                                                             "batch_size": cfg.dataloader.train.batch_size, "dataset": cfg.dataset.name if hasattr(cfg.dataset, "name") else None}}
     return loss.item(), g_img.cpu(), g_txt.cpu(), g_proj.cpu()
 
 
@@ -148,3 +153,78 @@ def test_rccl_one_rank_group_runs_every_exchange(dev):
     assert p.exitcode == 0
     assert abs(l_comm - l_plain) < 1e-5 * abs(l_plain), (l_comm, l_plain)
     assert max(rels) < 1e-3, rels          # atomics in the weight-gradient reductions reorder fp32 sums
+
+
+# ---- BASELINE config C3: train_prompt_clf, 2 ranks, global batch through the embedding all-gather ------------
+C3_OVERRIDES = ["networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_seqlen=77",
+                "networks.image_encoder.micro_batch=4", "networks.image_encoder.image_size=64"]     # dropout 0.2 etc. as shipped
+
+
+def _c3_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mmgclip import distributed
+    from mmgclip.dataset.synthetic import synthetic_batch
+    try:
+        comm = distributed.init_from_env("gloo")
+        batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=11)
+        n = 8 // world
+        mine = lambda: _slice_batch(batch, slice(rank * n, (rank + 1) * n))      # noqa: E731
+        over = _build_and_step(comm, mine(), "train_prompt_clf", C3_OVERRIDES, overlap=True, want_report=True)
+        after = _build_and_step(comm, mine(), "train_prompt_clf", C3_OVERRIDES, overlap=False, want_report=True)
+        q.put((rank, "ok", [over[0], over[1].numpy(), over[2].numpy(), over[3].numpy(), over[4]],
+               [after[0], after[1].numpy(), after[2].numpy(), after[3].numpy(), after[4]]))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+
+
+def test_config_c3_two_ranks_global_batch_and_both_gradient_sync_modes(dev):
+    """`train_prompt_clf` composed as shipped (CLIPLoss, dropout 0.2 group, dataloader_64) with the pixel towers, 2 ranks on halves of
+    a batch: the global-batch loss and the summed gradients equal the one-rank step on the whole batch; the bucketed / overlapped
+    gradient all-reduce and the MMG_GRAD_OVERLAP=0 fallback (one all-reduce per arena after the backward) give the same gradients,
+    and the `comm` report that bench.py prints at N > 1 is populated."""
+    from mmgclip.dataset.synthetic import synthetic_batch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_c3_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=400) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in results:
+        assert r[1] == "ok", r[2]
+    batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=11)
+    loss, gi, gt, gp = _build_and_step(None, _slice_batch(batch, slice(0, 8)), "train_prompt_clf", C3_OVERRIDES)
+    for rank, _, over, after in results:
+        rep = over[4]
+        assert (rep["cfg"]["loss"], rep["cfg"]["dropout"], rep["cfg"]["batch_size"]) == ("CLIPLoss", 0.2, 64), rep["cfg"]
+        for l2, gi2, gt2, gp2, _ in (over, after):
+            assert abs(l2 - loss) < 2e-3 * abs(loss), (rank, l2, loss)
+            for name, a, b in (("convnext", gi2, gi.numpy()), ("bert", gt2, gt.numpy()), ("proj", gp2, gp.numpy())):
+                cos = float(np.dot(a.ravel(), b.ravel()) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+                rel = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+                assert cos > 0.999 and rel < 5e-2, (rank, name, cos, rel)
+        # the two synchronisation modes reduce the same numbers (the towers' weight-gradient atomics reorder fp32 sums between two runs)
+        for a, b in zip(over[1:4], after[1:4]):
+            assert float(np.abs(a - b).max()) <= 1e-3 * float(np.abs(b).max()) + 1e-12
+        so, sa = over[4]["sync"], after[4]["sync"]
+        n_grad = gi.numel() + gt.numel() + gp.numel() * 2
+        assert so["mode"].startswith("bucketed") and sa["mode"].startswith("one all-reduce per arena")
+        assert so["grad_allreduce_bytes_per_step"] == sa["grad_allreduce_bytes_per_step"] >= 4 * (gi.numel() + gt.numel())
+        assert so["grad_allreduce_bytes_per_step"] <= 4 * n_grad + 64
+        assert sa["grad_allreduce_calls_per_step"] == 3.0 and so["grad_allreduce_calls_per_step"] >= 3.0     # two arenas + the heads
+        assert so["allreduce_busy_ms_per_step"] > 0 and so["exposed_wait_ms_per_step"] >= 0 and sa["exposed_wait_ms_per_step"] > 0
+        c = over[4]["comm"]
+        assert c["all_gather_calls"] == 4 and c["all_gather_bytes"] == 2 * (2 * 4 * 512 * 4) + 2 * (2 * 4 * 4)   # embeddings + LSE vectors
+    assert np.array_equal(results[0][2][1], results[1][2][1]) and np.array_equal(results[0][3][2], results[1][3][2])

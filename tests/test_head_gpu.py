@@ -115,6 +115,49 @@ def test_rank_simulated_global_loss(golden_dir, dev, P):
     assert abs(ds.item() - s.grad.item()) <= 1e-3 * abs(s.grad.item()) + 1e-6
 
 
+def test_config_c3_two_rank_head_matches_reference_golden(golden_dir, dev):
+    """BASELINE config C3's head: 2 ranks x 256 local pairs against the N = 512 global batch, D = 512.  Each simulated rank runs
+    `mmg_clip_rows_fwd` on its 256 rows against the gathered 512, the LSE vectors are exchanged, `mmg_clip_rows_bwd_fused` forms the
+    gradients of its own rows; loss and gradients w.r.t. the un-normalised projection outputs and the logit-scale parameter must equal
+    what the reference's CLIPLoss (losses.py:28-44) gives on the unsharded problem (tests/golden/g2_head_n512.npz)."""
+    from mmgclip import head
+    from mmgclip._hip import call, ptr, stream
+    g = np.load(os.path.join(golden_dir, "g2_head_n512.npz"))
+    img, txt = _t(g["img"], dev, True), _t(g["txt"], dev, True)
+    ie, te = head.L2Normalize.apply(img), head.L2Normalize.apply(txt)
+    scale = _t(g["scale"], dev).reshape(1)
+    N, D, P = 512, 512, 2
+    nl = N // P
+    assert ie.shape == (N, D)
+    ied, ted = ie.detach(), te.detach()
+    fw_i = [head.rows_forward(ied[r * nl:(r + 1) * nl].contiguous(), ted, scale, r * nl) for r in range(P)]
+    fw_t = [head.rows_forward(ted[r * nl:(r + 1) * nl].contiguous(), ied, scale, r * nl) for r in range(P)]
+    lse_i, lse_t = torch.cat([f[0] for f in fw_i]), torch.cat([f[0] for f in fw_t])          # the "all-gather" of exchange 2
+    loss = sum(((fi[0] - fi[1]).sum() + (ft[0] - ft[1]).sum()) for fi, ft in zip(fw_i, fw_t)) / (2 * N)   # the scalar all-reduce
+    assert abs(loss.item() - float(g["clip_loss"])) <= LOSS_RTOL * abs(float(g["clip_loss"])) + 1e-7
+    d_ie, d_te, ds = torch.empty_like(ied), torch.empty_like(ted), torch.zeros(1, device=dev)
+    for r in range(P):
+        sl = slice(r * nl, (r + 1) * nl)
+        x, y = ied[sl].contiguous(), ted[sl].contiguous()
+        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        call("mmg_clip_rows_bwd_fused", ptr(x), ptr(ted), ptr(scale), ptr(lse_i[sl].contiguous()), ptr(lse_t), None,
+             1.0 / (2 * N), nl, N, D, r * nl, ptr(dx), ptr(ds), stream())
+        call("mmg_clip_rows_bwd_fused", ptr(y), ptr(ied), ptr(scale), ptr(lse_t[sl].contiguous()), ptr(lse_i), None,
+             1.0 / (2 * N), nl, N, D, r * nl, ptr(dy), None, stream())
+        d_ie[sl], d_te[sl] = dx, dy
+    torch.autograd.backward([ie, te], [d_ie, d_te])
+    np.testing.assert_allclose(img.grad.cpu().numpy(), g["clip_dimg"], rtol=GRAD_RTOL, atol=GRAD_ATOL)
+    np.testing.assert_allclose(txt.grad.cpu().numpy(), g["clip_dtxt"], rtol=GRAD_RTOL, atol=GRAD_ATOL)
+    # d loss / d logit_scale_param = (summed over ranks) d loss / d s * s,  s = exp(param)
+    np.testing.assert_allclose(ds.item() * scale.item(), float(g["clip_dlogit_scale"]), rtol=GRAD_RTOL, atol=1e-6)
+    # and the product's own autograd function on the whole batch (P = 1) agrees with the two-rank arithmetic
+    img1, txt1 = _t(g["img"], dev, True), _t(g["txt"], dev, True)
+    l1 = head.fused_clip_loss(head.L2Normalize.apply(img1), head.L2Normalize.apply(txt1), scale.reshape(()))
+    l1.backward()
+    assert abs(l1.item() - loss.item()) <= 2e-6 * abs(loss.item())
+    np.testing.assert_allclose(img1.grad.cpu().numpy(), img.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
 def test_large_global_batch_properties(dev):
     """N = 8192 x D = 512 (config C5 shape): size-independent properties instead of a CPU oracle pass.
 

@@ -138,3 +138,39 @@ def test_label_prompt_sentences_and_oracle_scoring():
     np.random.seed(0)
     per, ci, acc, f1 = O.zeroshot_label_prompt(ie, te, 1 / 0.07, y, n_iterations=50)
     assert acc == 1.0 and f1 == 1.0 and all(a == 1.0 for a, _ in per) and ci == (1.0, 1.0, 1.0)
+
+
+def test_train_main_cli_composes_builds_loaders_and_constructs_the_experiment(tmp_path, monkeypatch):
+    """`train.main([...])` - the reference's entry point (train.py:9-90) - from the command line to the constructed experiment:
+    config name + group / key overrides parsed, seeded, the three synthetic loaders sized from the split ratios, the model / loss /
+    optimizer / scheduler built.  The epochs themselves need the GPU (tests/test_experiment_gpu.py runs one through the same entry)."""
+    import train
+    from mmgclip.experiments import ClassifierExperiment as CE
+    from mmgclip.networks import bert
+    orig = bert.BertConfigLite.__init__
+
+    def small(self, **kw):
+        kw.setdefault("num_hidden_layers", 1)
+        kw.setdefault("vocab_size", 2000)
+        orig(self, **kw)
+    monkeypatch.setattr(bert.BertConfigLite, "__init__", small)
+    ran = []
+    monkeypatch.setattr(CE.ClassifierExperiment, "run", lambda self: ran.append(self))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    exp = train.main(["--config-name", "train_prompt_clf", "networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_seqlen=77",
+                      "networks.image_encoder.image_size=64", "dataset.config.synthetic_samples=1000", "optimizer.config.learning_rate=0.001",
+                      f"checkpoints.checkpoints_export_dir={tmp_path}/ckpt", f"base.tensorboard_export_dir={tmp_path}/tb",
+                      f"base.results_export_dir={tmp_path}/results"])
+    assert ran == [exp] and type(exp).__name__ == "ClassifierExperiment"
+    cfg = exp.config
+    assert cfg.experiments.config.experiment_name == "classification" and cfg.loss.config.loss_name == "CLIPLoss"
+    assert cfg.networks.image_encoder.name == "ConvNextTinyEncoder" and cfg.tokenizer.config.sequence_length == 77
+    assert exp.optimizer.param_groups[0]["initial_lr"] == 0.001 and exp.optimizer.param_groups[0]["lr"] == 0.0     # epoch 1 runs at lr 0
+    # 1000 samples, 70 % train, half of the rest validation, batches of 64 (dataloader_64): 10 / 2 / 2 batches
+    assert (len(exp.train_dataloader), len(exp.valid_dataloader), len(exp.test_dataloader)) == (10, 2, 2)
+    b = next(iter(exp.test_dataloader))
+    assert b["image"].shape == (64, 1, 64, 64) and b["text_tokens"]["input_ids"].shape == (64, 77) and len(b["prompt_labels"]) == 64
+    assert type(exp.model).__name__ == "MMGCLIP" and type(exp.criterion).__name__ == "CLIPLoss"
+    assert torch.initial_seed() == cfg.base.seed == 42
+    with pytest.raises(ValueError, match="Invalid"):
+        train.main(["--config-name", "train_prompt_clf", "experiments.config.experiment_name=nope"])

@@ -78,6 +78,24 @@ def test_g2_sharded_equals_unsharded(golden_dir):
         assert abs(ds - float(sc.grad)) < 1e-4 * max(1e-3, abs(float(sc.grad)))
 
 
+def test_g2_config_c3_two_ranks(golden_dir):
+    """BASELINE config C3 (2 ranks x 256 pairs, N = 512, D = 512): the oracle's per-rank arithmetic (row blocks + LSE exchange, SURVEY
+    §8e) against the reference's CLIPLoss on the unsharded batch (g2_head_n512.npz, written by the reference's losses.py)."""
+    g = np.load(os.path.join(golden_dir, "g2_head_n512.npz"))
+    img, txt = _t(g["img"]).requires_grad_(True), _t(g["txt"]).requires_grad_(True)
+    ls = _t(g["logit_scale_param"]).requires_grad_(True)
+    ie, te, s = O.l2_normalize(img), O.l2_normalize(txt), ls.exp()
+    N, P = 512, 2
+    nl = N // P
+    parts = [(O.sharded_rows(ie[r * nl:(r + 1) * nl], te, s, r * nl), O.sharded_rows(te[r * nl:(r + 1) * nl], ie, s, r * nl)) for r in range(P)]
+    loss = sum(((a[0] - a[1]).sum() + (b[0] - b[1]).sum()) for a, b in parts) / (2 * N)
+    assert abs(float(loss) - float(g["clip_loss"])) <= 2e-6 * abs(float(g["clip_loss"]))
+    loss.backward()
+    np.testing.assert_allclose(img.grad.numpy(), g["clip_dimg"], rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(txt.grad.numpy(), g["clip_dtxt"], rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(ls.grad.numpy(), g["clip_dlogit_scale"], rtol=2e-4, atol=1e-6)
+
+
 def test_g3_averaged_loss_and_notebook_kats(golden_dir):
     g = np.load(os.path.join(golden_dir, "g3_averaged.npz"))
     labels = O.assign_labels(_t(g["nb_cos"]), 0.8)
