@@ -222,6 +222,22 @@ int mmg_cnblock_mlp_bwd(const void* dy, const void* xd, const float* ln_w, const
                         void* dxln, float* mean, float* rstd, float* ln_dw, float* ln_db, long long M, int C,
                         mmg_stream_t stream);
 
+/* CNBlock MLP backward with the weight gradients accumulated ON CHIP (round 3; C = 96, M a multiple of 64): nothing 4C-wide
+ * reaches HBM.  Two launches (csrc/cnblock_bwdw.hip): (1) h = LN(xd) W1^T + b1, g = GELU(h), dW2raw += dy^T g, db2raw += colsum(dy);
+ * (2) h again, dh = (dy gamma W2) * GELU'(h), dW1 += dh^T LN(xd), db1 += colsum(dh), d LN-out = dh W1, LayerNorm backward:
+ * dd = d loss / d xd (bf16 [M,C]), ln_dw / ln_db += LayerNorm weight / bias gradients.  All fp32 outputs are ACCUMULATED (atomics);
+ * dW2raw / db2raw are the un-scaled gradients mmg_layerscale_finalize expects (the same contract as dy^T g of the GEMM path).
+ * `packed` / `b1f` come from mmg_cnblock_bwdw_pack (bf16 mmg_cnblock_bwdw_packed_elems(C) elements; fp32 [4C]): the W1 LDS image,
+ * the LayerNorm-folded W1 and layer-scale-folded W2^T as per-wave MFMA fragments, and b1' = b1 + W1 ln_b.
+ * Replaces autograd of CNBlock.block[2..5] + layer_scale (torchvision ConvNeXt; the reference runs it frozen, encoder.py:53). */
+int mmg_cnblock_bwdw_supported(int C);
+long long mmg_cnblock_bwdw_packed_elems(int C);
+int mmg_cnblock_bwdw_pack(const float* w1, const float* w2, const float* ln_w, const float* ln_b, const float* layer_scale,
+                          const float* b1, void* packed, float* b1f, int C, mmg_stream_t stream);
+int mmg_cnblock_bwdw(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
+                     const float* b1f, void* dd, float* dW1, float* db1, float* dW2raw, float* db2raw, float* ln_dw,
+                     float* ln_db, long long M, int C, mmg_stream_t stream);
+
 /* ---- AveragedMedicalCLIPLoss helpers (reference mmgclip/loss/losses.py:98-216) ------------------------------------------------ */
 
 /* `_assign_labels` (losses.py:148-162) on the device: walking i = 0..n-1, an unlabelled text opens the next cluster and every

@@ -1,0 +1,472 @@
+// ConvNeXt block MLP backward with the weight gradients accumulated ON CHIP (C = 96: ConvNeXt-T stage 1).
+//
+// Replaces, for torchvision's CNBlock (reference: mmgclip/networks/encoder.py:53 runs `model.features`; module tree in
+// notebooks/clf_convnext_tiny_experimental.ipynb cell 3: LayerNorm -> Linear(C,4C) -> GELU -> Linear(4C,C) -> layer_scale -> residual),
+// the three launches of the round-1/2 backward - cnblock_mlp_bwd_kernel<96> (data path; writes g = GELU(h) and dh, 2 x [M,4C]) and
+// the two gemm_tn_wide_kernel<96,384> weight-gradient GEMMs that read them back: 70 GB of HBM traffic per block at 256 x 256 x 256
+// pixels, 52 GB of it the 4C-wide g / dh round trip.  Here nothing 4C-wide exists in HBM: the kernel reads dy and d (the depthwise
+// output) once, writes the gradient w.r.t. d once (6 M C bytes), and leaves through fp32 atomics of the weight / bias gradients once
+// per workgroup.
+//
+// Work split (one 8-wave workgroup per CU, persistent over 64-row tiles):
+//   * the HIDDEN dimension is split over the waves: wave w owns hidden units 48w .. 48w+47 for every row.  Its slices of
+//     dW2 = dy^T g ([96 x 48]) and dW1 = dh^T xhat ([48 x 96]) are 2 x 72 fp32 accumulator registers that stay put for the whole
+//     launch, the matching slices of the two weight matrices (W1 gamma_ln, gamma_ls W2^T; 9 KB each) are read as ready-made MFMA
+//     fragments from L2 (pre-packed by mmg_cnblock_bwdw_pack), and the rows of a tile come from LDS images that all waves share;
+//   * orientation: h = xhat (W1 gamma)^T is computed as D[row][hidden] (A = rows, B = weights), so a lane holds ONE hidden unit and
+//     4 consecutive rows per accumulator: bias + GELU / GELU' in place, and two such 16-row tiles ARE an MFMA operand whose k index is
+//     the row - the operand of the weight-gradient products - with no LDS round trip (guide: "an accumulator tile as the next MFMA's
+//     operand").  The other operand (dy^T / xhat^T, k = row) is a transposed read (ds_read_b64_tr_b16) of the same LDS row images the
+//     first two products read row-wise; a row-position permutation (quads 0 and 1 of every 16 rows exchanged) plus a pitch of
+//     72 rows per 16-byte column makes BOTH kinds of read conflict-free;
+//   * d LN-out = dh W1 contracts over the hidden index, which sits on the lanes: dh (bf16) goes through one LDS image
+//     [row tile][row quad][hidden] (8-byte pieces, conflict-free writes and transposed reads), and after a barrier every wave forms a
+//     [16 rows x 48 columns] piece of the product over ALL 384 hidden units against the W1 image that lives in LDS for the whole launch;
+//   * the LayerNorm backward runs on that product: gamma / beta gradients in the MFMA layout (xhat by one transposed read), the rows
+//     through an fp32 LDS tile in a row-per-8-lanes layout with 16-byte global accesses.
+// LayerNorm is folded: the row images hold xhat = (d - mean) rstd in bf16, gamma_ln multiplies the packed W1 of the first product and
+// beta enters through the bias b1' = b1 + W1 beta; the weight gradient is un-folded at the end (dW1 = gamma (dh^T xhat) + db1 beta^T).
+#include "common.h"
+#include <stdlib.h>
+
+#define BW_THREADS 512
+
+template <int C> struct BwCfg {
+    static constexpr int H4 = 4 * C;               // hidden width
+    static constexpr int R = 64;                   // rows per tile
+    static constexpr int HS = H4 / 8;              // hidden units per wave (48)
+    static constexpr int HT = HS / 16;             // 16-unit tiles per wave (3)
+    static constexpr int KS = C / 32;              // k-steps of the C-deep products (3)
+    static constexpr int CT = C / 16;              // 16-column tiles of a C-wide result (6)
+    static constexpr int KG = C / 8;               // 16-byte columns of a row image (12)
+    static constexpr int RP = R + 8;               // row pitch of the row images: 72 = 8 mod 16
+    static constexpr int NP1 = H4 + 8;             // hidden pitch of the W1 image and of the dh image: 392 = 8 mod 16
+    static constexpr int W1IMG = KG * NP1 * 16;    // bytes
+    static constexpr int ROWIMG = KG * RP * 16;
+    static constexpr int DHIMG = (R / 16) * 4 * NP1 * 8;
+    static constexpr int OFF_W1 = 0, OFF_X = W1IMG, OFF_DY = OFF_X + ROWIMG, OFF_DH = OFF_DY + ROWIMG;
+    static constexpr int OFF_LNW = OFF_DH + DHIMG, OFF_B1 = OFF_LNW + C * 4, OFF_STAT = OFF_B1 + H4 * 4;
+    static constexpr int LDS = OFF_STAT + 2 * R * 2 * 4;
+    // packed weight buffer (bf16 elements): [W1 LDS image][W1 gamma fragments][gamma_ls W2^T fragments]
+    static constexpr long PK_W1IMG = (long)KG * NP1 * 8;
+    static constexpr long PK_FRAGS = (long)8 * HT * KS * 64 * 8;
+    static constexpr long PK_TOTAL = PK_W1IMG + 2 * PK_FRAGS;
+    static_assert(R * C * 4 <= DHIMG, "the fp32 d LN-out tile aliases the dh image");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+struct BwArgs {
+    const bf16_t* dy; const bf16_t* xd;
+    const float* ln_w; const float* ln_b; float eps;
+    const bf16_t* packed; const float* b1f;
+    bf16_t* dd;
+    float* dW1; float* db1; float* dW2raw; float* db2raw; float* ln_dw; float* ln_db;
+    long M; int ntiles;
+};
+
+// position of row r (0..15) inside its 16-row group of a row image: quads 0 and 1 exchanged (see the header)
+__device__ __forceinline__ int bw_pos(int r) { return r < 8 ? (r ^ 4) : r; }
+
+__device__ __forceinline__ void bw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef __attribute__((address_space(3))) bf16x4 bw_lds_v4;
+__device__ __forceinline__ bf16x4 bw_tr(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bw_lds_v4*)p); }
+__device__ __forceinline__ bf16x8 bw_join(const bf16x4 lo, const bf16x4 hi) {
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ float bw_sum8(float v) {        // sum over the 8 lanes {8k .. 8k+7}
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    return v;
+}
+
+// MODE 1 ("cnblock_bwdw_w2_kernel"):  h = xhat (W1 gamma)^T + b1', g = GELU(h), dW2raw += dy^T g, db2raw += colsum(dy)
+// MODE 2 ("cnblock_bwdw_dx_kernel"):  h, dG = dy (gamma_ls W2), dh = dG GELU'(h), dW1 += un-folded dh^T xhat, db1 += colsum(dh),
+//                                     d LN-out = dh W1, LayerNorm backward -> dd, ln_dw, ln_db
+// Two launches instead of one because the two weight-gradient slices of a wave are 2 x 72 accumulator registers: together with the
+// ~100 live registers of the data path they do not fit the 256 a wave has at two waves per SIMD (hipcc spilled 36 ... 90 accumulator
+// registers to scratch in every arrangement tried - AGPR-pinned accumulators included, which the compiler splits 128 / 128), and one
+// wave per SIMD halves the VALU issue rate this GELU-bound kernel lives on.  The split costs one more h product (6 instead of 5
+// GEMM-equivalents per block) and no extra GELU work: GELU runs in launch 1, GELU' in launch 2.
+template <int C, int MODE>
+__global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArgs a) {
+    typedef BwCfg<C> Cfg;
+    constexpr int H4 = Cfg::H4, HT = Cfg::HT, KS = Cfg::KS, CT = Cfg::CT, RP = Cfg::RP, NP1 = Cfg::NP1, R = Cfg::R;
+    constexpr bool W2 = MODE == 1, DX = MODE == 2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* w1img = smem + Cfg::OFF_W1;
+    char* ximg = smem + Cfg::OFF_X;
+    char* dyimg = smem + Cfg::OFF_DY;
+    char* dhimg = smem + Cfg::OFF_DH;
+    float* s_dln = reinterpret_cast<float*>(smem + Cfg::OFF_DH);           // [R][C] fp32, aliases the dh image between barriers
+    float* s_lnw = reinterpret_cast<float*>(smem + Cfg::OFF_LNW);
+    float* s_b1 = reinterpret_cast<float*>(smem + Cfg::OFF_B1);            // b1' = b1 + W1 beta; reused for the db1 exchange at the end
+    float* s_stat = reinterpret_cast<float*>(smem + Cfg::OFF_STAT);        // [parity][R][mean, rstd]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+
+    // ---- prologue: the W1 image (global layout == LDS layout; launch 2 only), LayerNorm weight, folded bias --------------------
+    {
+        if (DX) {
+            const uint4* src = reinterpret_cast<const uint4*>(a.packed);
+            for (int i = tid; i < Cfg::W1IMG / 16; i += BW_THREADS) *reinterpret_cast<uint4*>(w1img + i * 16) = src[i];
+        }
+        for (int i = tid; i < C; i += BW_THREADS) s_lnw[i] = a.ln_w[i];
+        for (int i = tid; i < H4; i += BW_THREADS) s_b1[i] = a.b1f[i];
+    }
+    const bf16_t* w1g = a.packed + Cfg::PK_W1IMG + (long)wave * HT * KS * 512;        // this wave's fragments (512 bf16 each)
+    const bf16_t* w2g = w1g + Cfg::PK_FRAGS;
+
+    // ---- per-lane addresses -----------------------------------------------------------------------------------------------------
+    // staging (P0): lanes 0-31 take d, lanes 32-63 take dy; 8 rows per wave, 4 lanes per row, 3 pieces of 16 bytes per lane
+    const int st_half = lane >> 5, st_row = 8 * wave + (lane & 7), st_lg = (lane >> 3) & 3;
+    const int st_lds = ((st_lg * RP) + 16 * (st_row >> 4) + bw_pos(st_row & 15)) * 16;         // + ks * 4 * RP * 16
+    const bf16_t* st_src = (st_half ? a.dy : a.xd) + (long)st_row * C + 8 * st_lg;             // + tile * R * C + 32 * ks
+    // row-wise operand fragment (A of the C-deep products): row 16 rt + li, 16-byte column 4 ks + lg
+    const int rd_row = (lg * RP + bw_pos(li)) * 16;                                            // + ks * 4 * RP * 16 + rt * 256
+    // transposed reads of a row image: rows 4 lg + q of a 16-row tile, column piece p of a 16-column tile
+    const int tr_row = ((p >> 1) * RP + bw_pos(4 * lg + q)) * 16 + (p & 1) * 8;               // + ct * 2 * RP * 16 + rt * 256
+    // dh image: write 8 bytes = rows 4 lg .. +3 of hidden unit (own) ; transposed read: hidden 4 lg + q (+16), row piece p
+    const int dh_wr = (lg * NP1 + 48 * wave + li) * 8;                                          // + (rt * 4 * NP1 + 16 * ht) * 8
+    const int dh_rd = (p * NP1 + 4 * lg + q) * 8;                                               // + rt * 4 * NP1 * 8 + (32 ks [+16]) * 8
+    // W1 image, transposed: hidden 4 lg + q (+16), column piece p of column tile ct
+    const int w1_rd = ((p >> 1) * NP1 + 4 * lg + q) * 16 + (p & 1) * 8;                       // + ct * 2 * NP1 * 16 + (32 ks [+16]) * 16
+
+    f32x4 wacc[HT][CT];                        // MODE 1: dW2raw[c tile ct][hidden tile ht]; MODE 2: (dh^T xhat)[hidden tile ht][c tile ct]
+#pragma unroll
+    for (int i = 0; i < HT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bacc[HT] = {0.f, 0.f, 0.f};          // MODE 1: [0] = column sums of dy (wave w < 6: columns 16 w ..); MODE 2: db1 of the 3 hidden tiles
+    float dgacc[CT / 2] = {0.f, 0.f, 0.f}, dbacc[CT / 2] = {0.f, 0.f, 0.f};
+
+    bw_barrier();
+
+    uint4 pre[KS];
+    if ((int)blockIdx.x < a.ntiles) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) pre[ks] = *reinterpret_cast<const uint4*>(st_src + (long)blockIdx.x * R * C + 32 * ks);
+    }
+
+    int parity = 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
+        // ================= P0: rows -> LDS images (xhat, dy), row statistics =======================================================
+        {
+            char* img = st_half ? dyimg : ximg;
+            if (st_half == 0) {
+                // (three passes over the 12 packed registers instead of 24 unpacked floats)
+                float s = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned w[4] = {pre[ks].x, pre[ks].y, pre[ks].z, pre[ks].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s += bf2f_lo(w[e]) + bf2f_hi(w[e]);
+                }
+                s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+                const float mean = s * (1.0f / C);
+                float qq = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned w[4] = {pre[ks].x, pre[ks].y, pre[ks].z, pre[ks].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d0 = bf2f_lo(w[e]) - mean, d1 = bf2f_hi(w[e]) - mean; qq = fmaf(d0, d0, qq); qq = fmaf(d1, d1, qq); }
+                }
+                qq += __shfl_xor(qq, 8, 64); qq += __shfl_xor(qq, 16, 64);
+                const float rstd = rsqrtf(qq * (1.0f / C) + a.eps);
+                if (DX && st_lg == 0) { s_stat[(parity * R + st_row) * 2] = mean; s_stat[(parity * R + st_row) * 2 + 1] = rstd; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned w[4] = {pre[ks].x, pre[ks].y, pre[ks].z, pre[ks].w};
+                    unsigned o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack2bf((bf2f_lo(w[e]) - mean) * rstd, (bf2f_hi(w[e]) - mean) * rstd);
+                    *reinterpret_cast<uint4*>(img + st_lds + ks * (4 * RP * 16)) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<uint4*>(img + st_lds + ks * (4 * RP * 16)) = pre[ks];
+            }
+        }
+        bw_barrier();                                                                                    // A
+        // next tile's rows: requested now, consumed at its P0
+        if (tile + (int)gridDim.x < a.ntiles) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                pre[ks] = *reinterpret_cast<const uint4*>(st_src + (long)(tile + gridDim.x) * R * C + 32 * ks);
+        }
+
+        // ================= P1: this wave's 48 hidden units over the 64 rows ==========================================================
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+            bf16x8 w1f[KS], w2f[DX ? KS : 1];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 u1 = *reinterpret_cast<const uint4*>(w1g + ((ht * KS + ks) * 64 + lane) * 8);
+                w1f[ks] = __builtin_bit_cast(bf16x8, (u32x4_t{u1.x, u1.y, u1.z, u1.w}));
+                if (DX) {
+                    const uint4 u2 = *reinterpret_cast<const uint4*>(w2g + ((ht * KS + ks) * 64 + lane) * 8);
+                    w2f[ks] = __builtin_bit_cast(bf16x8, (u32x4_t{u2.x, u2.y, u2.z, u2.w}));
+                }
+            }
+            const float bias = s_b1[48 * wave + 16 * ht + li];
+            float dbsum = 0.f;
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                f32x4 hacc[2], gacc[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) { hacc[t2] = f32x4{bias, bias, bias, bias}; gacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        const int off = rd_row + ks * (4 * RP * 16) + (2 * rp + t2) * 256;
+                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(ximg + off);
+                        hacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, w1f[ks], hacc[t2], 0, 0, 0);
+                        if (DX) {
+                            const bf16x8 df = *reinterpret_cast<const bf16x8*>(dyimg + off);
+                            gacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, w2f[ks], gacc[t2], 0, 0, 0);
+                        }
+                    }
+                // GELU (launch 1) / GELU' (launch 2) in place: lane = hidden unit 48 w + 16 ht + li, rows 16 (2 rp + t2) + 4 lg + e
+                unsigned op[4];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (W2) v[e] = gelu_bf16(hacc[t2][e]);
+                        else { v[e] = gacc[t2][e] * gelu_bf16_grad(hacc[t2][e]); dbsum += v[e]; }
+                    }
+                    op[2 * t2] = pack2bf(v[0], v[1]); op[2 * t2 + 1] = pack2bf(v[2], v[3]);
+                    if (DX) *reinterpret_cast<uint2*>(dhimg + dh_wr + ((2 * rp + t2) * 4 * NP1 + 16 * ht) * 8) = make_uint2(op[2 * t2], op[2 * t2 + 1]);
+                }
+                const bf16x8 of = __builtin_bit_cast(bf16x8, (u32x4_t{op[0], op[1], op[2], op[3]}));       // g (launch 1) / dh (launch 2)
+                // weight gradient: k = the 32 rows of this pair of row tiles (slot 8 lg + j: j < 4 row 4 lg + j, else 16 + 4 lg + j - 4)
+                const char* timg = W2 ? dyimg : ximg;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int off = tr_row + ct * (2 * RP * 16) + (2 * rp) * 256;
+                    const bf16x8 tT = bw_join(bw_tr(timg + off), bw_tr(timg + off + 256));
+                    if (W2) {          // D[c][hidden] += dy^T[c][row] g[row][hidden]
+                        wacc[ht][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT, of, wacc[ht][ct], 0, 0, 0);
+                        if (ht == 0) {          // bias gradient of the second linear: column sums of dy; wave w < 6 keeps columns 16 w ..
+                            float sy = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sy += bf2f((bf16_t)tT[e]);
+                            bacc[0] += (ct == wave) ? sy : 0.f;
+                        }
+                    } else {           // D[hidden][c] += dh^T[hidden][row] xhat[row][c]
+                        wacc[ht][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, tT, wacc[ht][ct], 0, 0, 0);
+                    }
+                }
+            }
+            if (DX) bacc[ht] += dbsum;
+        }
+        bw_barrier();                                                                                    // B: images consumed (launch 2: the dh image is complete)
+        if (DX) {
+            // ================= P2: d LN-out = dh W1 for (row tile rt, 3 column tiles), gamma / beta gradients ========================
+            const int rt = wave >> 1, ch = wave & 1;
+            f32x4 lacc[CT / 2];
+#pragma unroll
+            for (int c3 = 0; c3 < CT / 2; ++c3) lacc[c3] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int ks = 0; ks < H4 / 32; ++ks) {
+                const char* pa = dhimg + dh_rd + rt * (4 * NP1 * 8) + ks * (32 * 8);
+                const bf16x8 af = bw_join(bw_tr(pa), bw_tr(pa + 16 * 8));
+#pragma unroll
+                for (int c3 = 0; c3 < CT / 2; ++c3) {
+                    const char* pb = w1img + w1_rd + (3 * ch + c3) * (2 * NP1 * 16) + ks * (32 * 16);
+                    const bf16x8 bf = bw_join(bw_tr(pb), bw_tr(pb + 16 * 16));
+                    lacc[c3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, lacc[c3], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int c3 = 0; c3 < CT / 2; ++c3) {
+                const bf16x4 xh = bw_tr(ximg + tr_row + (3 * ch + c3) * (2 * RP * 16) + rt * 256);          // xhat[16 rt + 4 lg + e][16 ct + li]
+                float sg = 0.f, sb = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sb += lacc[c3][e]; sg = fmaf(lacc[c3][e], bf2f((bf16_t)xh[e]), sg); }
+                dgacc[c3] += sg; dbacc[c3] += sb;
+            }
+            bw_barrier();                                                                                // C1: dh image has been read
+#pragma unroll
+            for (int c3 = 0; c3 < CT / 2; ++c3)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s_dln[(16 * rt + 4 * lg + e) * C + 16 * (3 * ch + c3) + li] = lacc[c3][e];
+            bw_barrier();                                                                                // C2
+
+            // ================= P3: LayerNorm backward, one row per 8 lanes (6 of them active, 16 columns each) =======================
+            const int row = tid >> 3, part = tid & 7;
+            const bool act = part < CT;
+            const int c0 = act ? 16 * part : 0;
+            const long grow = (long)tile * R + row;
+            const float mean = s_stat[(parity * R + row) * 2], rstd = s_stat[(parity * R + row) * 2 + 1];
+            float x[16];
+            float s1 = 0.f, s2 = 0.f;
+            if (act) {
+                const uint4 d0 = *reinterpret_cast<const uint4*>(a.xd + grow * C + c0);
+                const uint4 d1 = *reinterpret_cast<const uint4*>(a.xd + grow * C + c0 + 8);
+                const unsigned w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[2 * e] = (bf2f_lo(w[e]) - mean) * rstd; x[2 * e + 1] = (bf2f_hi(w[e]) - mean) * rstd; }
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const f32x4 dl = *reinterpret_cast<const f32x4*>(s_dln + row * C + c0 + 4 * v4);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + c0 + 4 * v4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float g = dl[e] * gm[e]; s1 += g; s2 = fmaf(g, x[4 * v4 + e], s2); }
+                }
+            }
+            s1 = bw_sum8(s1); s2 = bw_sum8(s2);
+            if (act) {
+                const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8) {          // second pass over the LDS tile: 8 columns per 16-byte store
+                    unsigned o[4];
+#pragma unroll
+                    for (int v4 = 0; v4 < 2; ++v4) {
+                        const f32x4 dl = *reinterpret_cast<const f32x4*>(s_dln + row * C + c0 + 8 * h8 + 4 * v4);
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + c0 + 8 * h8 + 4 * v4);
+                        float r4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r4[e] = rstd * (fmaf(-x[8 * h8 + 4 * v4 + e], m2, dl[e] * gm[e]) - m1);
+                        o[2 * v4] = pack2bf(r4[0], r4[1]); o[2 * v4 + 1] = pack2bf(r4[2], r4[3]);
+                    }
+                    *reinterpret_cast<uint4*>(a.dd + grow * C + c0 + 8 * h8) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            // (no barrier: the next P0 writes the row images and the other parity of s_stat; s_dln is rewritten as the dh image only
+            //  after the next tile's barrier A, which every wave reaches after its P3)
+        }
+    }
+
+    // ================= epilogue: the accumulators leave as fp32 atomics =================================================================
+    bw_barrier();
+    if (W2) {
+        if (wave < CT) {
+            float v = bacc[0];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lg == 0) atomicAdd(a.db2raw + 16 * wave + li, v);
+        }
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)       // dW2raw[c = 16 ct + 4 lg + e][hidden 48 w + 16 ht + li]
+                    atomicAdd(a.dW2raw + (long)(16 * ct + 4 * lg + e) * H4 + 48 * wave + 16 * ht + li, wacc[ht][ct][e]);
+    } else {
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+            float v = bacc[ht];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lg == 0) { s_b1[48 * wave + 16 * ht + li] = v; atomicAdd(a.db1 + 48 * wave + 16 * ht + li, v); }
+        }
+        const int ch = wave & 1;
+#pragma unroll
+        for (int c3 = 0; c3 < CT / 2; ++c3) {
+            float g = dgacc[c3], b = dbacc[c3];
+            g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (lg == 0) { atomicAdd(a.ln_dw + 16 * (3 * ch + c3) + li, g); atomicAdd(a.ln_db + 16 * (3 * ch + c3) + li, b); }
+        }
+        bw_barrier();
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = 16 * ct + li;
+                const float gm = s_lnw[c], bt = a.ln_b[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // dW1[hidden 48 w + 16 ht + 4 lg + e][c] = gamma[c] (dh^T xhat) + beta[c] db1[hidden]   (un-folding of the LayerNorm affine)
+                    const int n = 48 * wave + 16 * ht + 4 * lg + e;
+                    atomicAdd(a.dW1 + (long)n * C + c, fmaf(gm, wacc[ht][ct][e], bt * s_b1[n]));
+                }
+            }
+    }
+}
+
+// ---- weight packing ------------------------------------------------------------------------------------------------------------------
+struct BwPack { const float* w1; const float* w2; const float* ln_w; const float* ln_b; const float* ls; const float* b1; bf16_t* out; float* b1f; int C; };
+
+template <int C>
+__global__ __launch_bounds__(256) void cnblock_bwdw_pack_kernel(const BwPack a) {
+    typedef BwCfg<C> Cfg;
+    constexpr int H4 = Cfg::H4, NP1 = Cfg::NP1, KS = Cfg::KS, HT = Cfg::HT;
+    const long total = Cfg::PK_TOTAL;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + H4; e += (long)gridDim.x * blockDim.x) {
+        if (e >= total) {                         // b1' = b1 + W1 beta
+            const int n = (int)(e - total);
+            float s = a.b1[n];
+            for (int c = 0; c < C; ++c) s = fmaf(a.w1[(long)n * C + c], a.ln_b[c], s);
+            a.b1f[n] = s;
+            continue;
+        }
+        float v;
+        if (e < Cfg::PK_W1IMG) {                  // [16-byte column kg][hidden, pitch NP1][8]: plain W1 (the d LN-out product)
+            const int kg = (int)(e / (NP1 * 8)), n = (int)((e / 8) % NP1), j = (int)(e % 8);
+            v = n < H4 ? a.w1[(long)n * C + 8 * kg + j] : 0.f;
+        } else {                                  // fragments: [which][wave][ht][ks][lane][8]: B[k = c = 32 ks + 8 lg + j][hidden 48 w + 16 ht + li]
+            long f = e - Cfg::PK_W1IMG;
+            const int which = (int)(f / Cfg::PK_FRAGS);
+            f -= (long)which * Cfg::PK_FRAGS;
+            const int j = (int)(f % 8), lane = (int)((f / 8) % 64), ks = (int)((f / 512) % KS), ht = (int)((f / (512 * KS)) % HT);
+            const int w = (int)(f / (512 * KS * HT));
+            const int n = 48 * w + 16 * ht + (lane & 15), c = 32 * ks + 8 * (lane >> 4) + j;
+            v = which == 0 ? a.w1[(long)n * C + c] * a.ln_w[c]                 // W1 gamma_ln  (LayerNorm affine folded)
+                           : a.w2[(long)c * H4 + n] * a.ls[c];                 // gamma_ls W2^T (layer scale folded: dG = dy (gamma W2))
+        }
+        a.out[e] = f2bf(v);
+    }
+}
+
+static int bw_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t pr;
+        (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+MMG_API int mmg_cnblock_bwdw_supported(int C) { return C == 96 ? 1 : 0; }
+MMG_API long long mmg_cnblock_bwdw_packed_elems(int C) { return C == 96 ? (long long)BwCfg<96>::PK_TOTAL : 0; }
+
+MMG_API int mmg_cnblock_bwdw_pack(const float* w1, const float* w2, const float* ln_w, const float* ln_b, const float* layer_scale,
+                                  const float* b1, void* packed, float* b1f, int C, hipStream_t stream) {
+    MMG_CHECK_ARG(C == 96, "mmg_cnblock_bwdw_pack: C=%d is not supported (96)", C);
+    MMG_CHECK_ARG(w1 && w2 && ln_w && ln_b && layer_scale && b1 && packed && b1f, "mmg_cnblock_bwdw_pack: null pointer");
+    BwPack a{w1, w2, ln_w, ln_b, layer_scale, b1, (bf16_t*)packed, b1f, C};
+    hipLaunchKernelGGL(cnblock_bwdw_pack_kernel<96>, dim3(128), dim3(256), 0, stream, a);
+    MMG_LAUNCH_CHECK("mmg_cnblock_bwdw_pack");
+    return 0;
+}
+
+MMG_API int mmg_cnblock_bwdw(const void* dy, const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
+                             const float* b1f, void* dd, float* dW1, float* db1, float* dW2raw, float* db2raw, float* ln_dw,
+                             float* ln_db, long long M, int C, hipStream_t stream) {
+    MMG_CHECK_ARG(C == 96, "mmg_cnblock_bwdw: C=%d is not supported (96)", C);
+    MMG_CHECK_ARG(M > 0 && M % BwCfg<96>::R == 0, "mmg_cnblock_bwdw: M=%lld must be a positive multiple of %d", M, BwCfg<96>::R);
+    MMG_CHECK_ARG(dy && xd && ln_w && ln_b && packed && b1f && dd && dW1 && db1 && dW2raw && db2raw && ln_dw && ln_db,
+                  "mmg_cnblock_bwdw: null pointer");
+    BwArgs a;
+    a.dy = (const bf16_t*)dy; a.xd = (const bf16_t*)xd; a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps;
+    a.packed = (const bf16_t*)packed; a.b1f = b1f; a.dd = (bf16_t*)dd;
+    a.dW1 = dW1; a.db1 = db1; a.dW2raw = dW2raw; a.db2raw = db2raw; a.ln_dw = ln_dw; a.ln_db = ln_db;
+    a.M = M; a.ntiles = (int)(M / BwCfg<96>::R);
+    const int cap = bw_cu_count();
+    const int grid = a.ntiles < cap ? a.ntiles : cap;
+    mmg_allow_lds(cnblock_bwdw_kernel<96, 1>, BwCfg<96>::LDS);
+    mmg_allow_lds(cnblock_bwdw_kernel<96, 2>, BwCfg<96>::LDS);
+    MMG_NOTE_KERNEL("cnblock_bwdw_kernel<96, *>");
+    hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1>), dim3(grid), dim3(BW_THREADS), BwCfg<96>::LDS, stream, a);
+    hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 2>), dim3(grid), dim3(BW_THREADS), BwCfg<96>::LDS, stream, a);
+    MMG_LAUNCH_CHECK("mmg_cnblock_bwdw");
+    return 0;
+}

@@ -212,6 +212,34 @@ def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None, ln_grads
     return dh, g, xln, dxln, mean, rstd
 
 
+def cnblock_bwdw_supported(C, M):
+    """On-chip weight-gradient backward of the CNBlock MLP (csrc/cnblock_bwdw.hip): C = 96, M a multiple of 64."""
+    return bool(_hip.load().mmg_cnblock_bwdw_supported(C)) and M % 64 == 0
+
+
+def cnblock_bwdw_pack(w1, w2, ln_w, ln_b, layer_scale, b1):
+    """-> (packed bf16 buffer, b1' fp32 [4C]) for cnblock_bwdw."""
+    C = w1.shape[1]
+    n = _hip.load().mmg_cnblock_bwdw_packed_elems(C)
+    if n <= 0:
+        raise ValueError(f"on-chip weight-gradient CNBlock backward: C={C} is not supported")
+    packed = torch.empty(n, device=w1.device, dtype=BF16)
+    b1f = torch.empty(4 * C, device=w1.device, dtype=torch.float32)
+    call("mmg_cnblock_bwdw_pack", ptr(w1), ptr(w2), ptr(ln_w), ptr(ln_b), ptr(layer_scale), ptr(b1), ptr(packed), ptr(b1f), C, stream())
+    return packed, b1f
+
+
+def cnblock_bwdw(dy, xd, ln_w, ln_b, eps, packed, b1f, dW1, db1, dW2raw, db2raw, ln_dw, ln_db):
+    """-> dd [M,C] bf16; accumulates the six fp32 gradient buffers (see include/mmgclip_hip.h)."""
+    M, C = xd.shape
+    dd = torch.empty_like(xd)
+    # algorithmic work: dG, dW2, dW1, d LN-out products (the two recomputed h products are overhead); reads dy, xd twice, writes dd
+    PROFILE.timed("cnblock_bwdw_kernel", 32.0 * M * C * C, 10 * M * C + 24 * C * C,
+                  lambda: call("mmg_cnblock_bwdw", ptr(dy), ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed), ptr(b1f), ptr(dd),
+                               ptr(dW1), ptr(db1), ptr(dW2raw), ptr(db2raw), ptr(ln_dw), ptr(ln_db), M, C, stream()), f"M={M} C={C}")
+    return dd
+
+
 def attention_fwd(qkv, mask, B, S, heads, want_lse=True, force_long=False, cu=None):
     """Whole-sequence-in-LDS kernel up to S = 512, flash-style tiled kernel beyond (or when force_long).
     cu (int32 [B+1]): packed layout, rows cu[b]..cu[b+1] are sequence b (S = longest sequence, mask unused)."""

@@ -271,19 +271,20 @@ def test_fused_adamw_loads_a_reference_style_state_dict_with_frozen_bert(dev, tm
 
 def test_train_main_runs_one_tiny_epoch_and_the_end_of_run_test_pass(dev, tmp_path, monkeypatch):
     """The whole drop-in chain through `train.main([...])` (reference train.py:9-90 -> ClassifierExperiment.run -> test ->
-    Evaluator.evaluate_experiment, ClassifierExperiment.py:291-301,337-339, evaluator.py:564-654) on synthetic loaders: one epoch,
+    Evaluator.evaluate_experiment, ClassifierExperiment.py:291-301,337-339, evaluator.py:564-654) on synthetic loaders: two epochs (the
+    first one at lr 0, as the reference's schedule has it),
     a checkpoint, and results.txt from the zero-shot label-prompt scorer over the test split."""
     import train
     restore = _small_bert()
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     try:
         exp = train.main(["--config-name", "train_binary_class_clf"] + PIXELS[:-1] + [
-            "scheduler=warmup1_epo15", "scheduler.config.epochs=1", "dataset.config.synthetic_samples=64", "dataloader=dataloader_32",
+            "scheduler=warmup1_epo15", "scheduler.config.epochs=2", "dataset.config.synthetic_samples=64", "dataloader=dataloader_32",
             "optimizer.config.fused=true", f"checkpoints.checkpoints_export_dir={tmp_path}/ckpt",
             f"base.tensorboard_export_dir={tmp_path}/tb", f"base.results_export_dir={tmp_path}/results"])
     finally:
         restore()
-    assert exp.current_epoch == 0 and os.path.isfile(os.path.join(str(tmp_path), "ckpt", "model.pth"))
+    assert exp.current_epoch == 1 and os.path.isfile(os.path.join(str(tmp_path), "ckpt", "model.pth"))
     assert list(exp.config.dataset.eval.enum_classes) == ["BenignMalignantDatasetLabels"]
     (res,) = exp.test_results                       # one enum class x the one scorer this build has ("ova" / "confustion_matrix" skipped)
     assert set(res) == {"Finding suggesting benign.", "Finding suggesting malignant.", "auc_ci_mean", "auc_ci_lower", "auc_ci_higher",

@@ -346,6 +346,55 @@ def test_fused_cnblock_mlp_backward_with_layernorm_backward(dev, C, M):
     assert rel(dw - 0.5, dw_want) < 2e-2 and rel(db + 0.25, db_want) < 2e-2, (rel(dw - 0.5, dw_want), rel(db + 0.25, db_want))
 
 
+@pytest.mark.parametrize("M", [64, 64 * 5, 64 * 300])
+def test_cnblock_backward_with_on_chip_weight_gradients(dev, M):
+    """mmg_cnblock_bwdw (round 3: the stage-1 block backward whose g / dh never reach HBM) vs fp32 torch autograd of
+    LN -> Linear -> GELU -> Linear -> layer scale: d loss / d xd, both weight gradients in the contract of the GEMM path
+    (dW2raw = dy^T g un-scaled, dW1, db1, db2raw = colsum dy) and the LayerNorm weight / bias gradients; every fp32 output is
+    ACCUMULATED into what the buffer held.  M = 64 * 300 runs more tiles than the persistent grid has workgroups."""
+    from mmgclip import kernels as K
+    C = 96
+    g_ = torch.Generator().manual_seed(13 * C + M)
+    xd = (torch.randn(M, C, generator=g_) * 1.5 + 0.3).to(torch.bfloat16)
+    dy = (0.5 * torch.randn(M, C, generator=g_)).to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * torch.randn(C, generator=g_), 0.1 * torch.randn(C, generator=g_)
+    w1, b1 = torch.randn(4 * C, C, generator=g_) / C ** 0.5, 0.1 * torch.randn(4 * C, generator=g_)
+    w2 = torch.randn(C, 4 * C, generator=g_) / (4 * C) ** 0.5
+    ls = 0.3 + 0.7 * torch.rand(C, generator=g_)
+    assert K.cnblock_bwdw_supported(C, M) and not K.cnblock_bwdw_supported(C, M + 1) and not K.cnblock_bwdw_supported(192, M)
+    # fp64 reference of the same maths (no bf16 roundings inside: the kernel's are what the tolerances below allow for)
+    x = xd.double().requires_grad_(True)
+    pw, pb = lnw.double().requires_grad_(True), lnb.double().requires_grad_(True)
+    W1, B1 = w1.double().requires_grad_(True), b1.double().requires_grad_(True)
+    h = F.layer_norm(x, (C,), pw, pb, 1e-6) @ W1.t() + B1
+    gl = F.gelu(h)
+    dG = dy.double() @ (w2.double() * ls.double()[:, None])           # gradient w.r.t. the GELU output (layer scale folded)
+    dx_want, dlw_want, dlb_want, dW1_want, db1_want = torch.autograd.grad(gl, (x, pw, pb, W1, B1), dG)
+    dW2raw_want = dy.double().t() @ gl.detach()
+    db2raw_want = dy.double().sum(0)
+    d = lambda t: t.to(dev)   # noqa: E731
+    packed, b1f = K.cnblock_bwdw_pack(d(w1), d(w2), d(lnw), d(lnb), d(ls), d(b1))
+    assert float((b1f.cpu().double() - (b1.double() + w1.double() @ lnb.double())).abs().max()) < 1e-5
+    bufs = {k: torch.full(shape, v, device=dev) for k, shape, v in (("dW1", (4 * C, C), 0.25), ("db1", (4 * C,), -1.0), ("dW2raw", (C, 4 * C), 0.5),
+                                                                    ("db2raw", (C,), 2.0), ("ln_dw", (C,), 0.5), ("ln_db", (C,), -0.25))}
+    dd = K.cnblock_bwdw(d(dy), d(xd), d(lnw), d(lnb), 1e-6, packed, b1f, bufs["dW1"], bufs["db1"], bufs["dW2raw"], bufs["db2raw"],
+                        bufs["ln_dw"], bufs["ln_db"])
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())   # noqa: E731
+    errs = {"dd": rel(dd.float(), dx_want), "dW1": rel(bufs["dW1"] - 0.25, dW1_want), "db1": rel(bufs["db1"] + 1.0, db1_want),
+            "dW2raw": rel(bufs["dW2raw"] - 0.5, dW2raw_want), "db2raw": rel(bufs["db2raw"] - 2.0, db2raw_want),
+            "ln_dw": rel(bufs["ln_dw"] - 0.5, dlw_want), "ln_db": rel(bufs["ln_db"] + 0.25, dlb_want)}
+    from tests.conftest import measured
+    measured("cnblock_bwdw", M=M, **errs)
+    # bf16 operands (8 significant bits) through three products: the same bars as the GEMM-path tests above (2e-2 ... 3e-2)
+    assert errs["dd"] < 2e-2 and errs["dW1"] < 2e-2 and errs["dW2raw"] < 2e-2, errs
+    assert errs["db1"] < 2e-2 and errs["db2raw"] < 1e-3 and errs["ln_dw"] < 2e-2 and errs["ln_db"] < 2e-2, errs
+    _close(dd, dx_want.float(), 3e-2, 3e-2)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        K.cnblock_bwdw(d(dy)[:63], d(xd)[:63], d(lnw), d(lnb), 1e-6, packed, b1f, bufs["dW1"], bufs["db1"], bufs["dW2raw"], bufs["db2raw"],
+                       bufs["ln_dw"], bufs["ln_db"])
+
+
 # ---- fp8 (e4m3) operand producers --------------------------------------------------------------------------------------------
 def test_quantize_e4m3_matches_the_oracle_bytes(dev):
     """scale is a power of two, so src * scale is exact: bytes and scales must equal the oracle's bit for bit."""
