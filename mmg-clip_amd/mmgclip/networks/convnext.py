@@ -91,6 +91,7 @@ class ConvNextTower(nn.Module):
         # narrow stages (C <= 256) run the CNBlock MLP as one fused launch; MMG_FUSED_MLP=0 keeps the GEMM pair
         self.fused_mlp = (os.environ.get("MMG_FUSED_MLP", "1") != "0") if fused_mlp is None else bool(fused_mlp)
         self.fused_bwd_saved_h = os.environ.get("MMG_FUSED_MLP_BWD_SAVED_H", "0") == "1"
+        self.bwdw = os.environ.get("MMG_BWDW", "1") != "0"        # on-chip weight-gradient backward where supported (csrc/cnblock_bwdw.hip)
         # blocks whose backward is the GEMM pair keep their LayerNorm output ([M,C] bf16) instead of recomputing it - decided per forward:
         # only while those copies stay below 4 % of the device memory (C2: 8.4 GB on; ConvNeXt-B at 256 images without checkpointing:
         # 31 GB on top of 267 GiB of activations, off).  MMG_SAVE_LN=0 / 1 force it.
@@ -160,6 +161,10 @@ class ConvNextTower(nn.Module):
                     if mode:
                         wc[key + (".mlpb" if mode == 1 else ".mlpb2")] = K.cnblock_pack(
                             blk.block[3].weight.data, blk.block[5].weight.data, blk.layer_scale.data.reshape(C), backward=mode)
+                    # round 3: backward with the weight gradients accumulated on chip (C = 96: nothing 4C-wide reaches HBM)
+                    if mode == 1 and self.bwdw and K.cnblock_bwdw_supported(C, 64):
+                        wc[key + ".bwdw"] = K.cnblock_bwdw_pack(blk.block[3].weight.data, blk.block[5].weight.data, blk.block[2].weight.data,
+                                                                blk.block[2].bias.data, blk.layer_scale.data.reshape(C), blk.block[3].bias.data)
             if si < 3:
                 conv = f[2 + 2 * si][1].weight.data                                          # [2C, C, 2, 2]
                 wds = conv.permute(0, 2, 3, 1).reshape(conv.shape[0], -1).contiguous()       # [(kh,kw,ci)]
@@ -266,7 +271,15 @@ class ConvNextTower(nn.Module):
                 blk = f[1 + 2 * si][bi]
                 key = f"{si}.{bi}"
                 x, d, mean, rstd, hpre, ln_saved = saved[key]
-                if hpre is None or key + ".mlpb2" in wc:   # fused data path (hidden row recomputed on chip / read back)
+                if hpre is None and key + ".bwdw" in wc and K.cnblock_bwdw_supported(C, d.shape[0]):
+                    # stage 1: data path AND both weight gradients in two launches that read dx, d and write dd - the g / dh tensors
+                    # ([M,4C] each) of the path below and its two weight-gradient GEMMs do not exist
+                    packed, b1f = wc[key + ".bwdw"]
+                    dd = K.cnblock_bwdw(dx, d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, packed, b1f,
+                                        gname(blk.block[3], "weight"), gname(blk.block[3], "bias"), tmp[key + ".dw2raw"], tmp[key + ".db2raw"],
+                                        gname(blk.block[2], "weight"), gname(blk.block[2], "bias"))
+                    dln = None
+                elif hpre is None or key + ".mlpb2" in wc:   # fused data path (hidden row recomputed on chip / read back)
                     # C <= 128: the LayerNorm backward rides in the epilogue (`dd` comes back instead of d LN-out); wider
                     # blocks have no registers left for it
                     fuse_ln = C <= 128
