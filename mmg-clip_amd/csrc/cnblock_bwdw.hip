@@ -200,22 +200,51 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
         }
 
         // ================= P1: this wave's 48 hidden units over the 64 rows ==========================================================
-#pragma unroll
-        for (int ht = 0; ht < HT; ++ht) {
+        // Six steps (row-tile pair rp, hidden tile ht), rp outer.  Every operand is requested well before its use and lives in ONE
+        // register set that is re-loaded right after its last use (hipcc, left alone, emitted `ds_read; s_waitcnt lgkmcnt(0); mfma` per
+        // MFMA on a single fragment register: 58 % of the wave time parked at waits, PMC round 3):
+        //   row fragments (xhat, dy rows of this rp)   once per rp, loaded after the last product of the previous rp
+        //   transposed fragments (k = rows)            once per rp, loaded after the last weight-gradient product of the previous rp
+        //   weight fragments of the next step          requested from L2 right after this step's products, landing under the GELU block
+        {
             bf16x8 w1f[KS], w2f[DX ? KS : 1];
+            bf16x8 xa[KS][2], da[DX ? KS : 1][2];
+            bf16x8 tT[CT];
+            const char* timg = W2 ? dyimg : ximg;
+            auto load_w = [&](int ht) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const uint4 u1 = *reinterpret_cast<const uint4*>(w1g + ((ht * KS + ks) * 64 + lane) * 8);
-                w1f[ks] = __builtin_bit_cast(bf16x8, (u32x4_t{u1.x, u1.y, u1.z, u1.w}));
-                if (DX) {
-                    const uint4 u2 = *reinterpret_cast<const uint4*>(w2g + ((ht * KS + ks) * 64 + lane) * 8);
-                    w2f[ks] = __builtin_bit_cast(bf16x8, (u32x4_t{u2.x, u2.y, u2.z, u2.w}));
+                for (int ks = 0; ks < KS; ++ks) {
+                    const uint4 u1 = *reinterpret_cast<const uint4*>(w1g + ((ht * KS + ks) * 64 + lane) * 8);
+                    w1f[ks] = __builtin_bit_cast(bf16x8, (u32x4_t{u1.x, u1.y, u1.z, u1.w}));
+                    if (DX) {
+                        const uint4 u2 = *reinterpret_cast<const uint4*>(w2g + ((ht * KS + ks) * 64 + lane) * 8);
+                        w2f[ks] = __builtin_bit_cast(bf16x8, (u32x4_t{u2.x, u2.y, u2.z, u2.w}));
+                    }
                 }
-            }
-            const float bias = s_b1[48 * wave + 16 * ht + li];
-            float dbsum = 0.f;
+            };
+            auto load_a = [&](int rp) {
 #pragma unroll
-            for (int rp = 0; rp < 2; ++rp) {
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        const int off = rd_row + ks * (4 * RP * 16) + (2 * rp + t2) * 256;
+                        xa[ks][t2] = *reinterpret_cast<const bf16x8*>(ximg + off);
+                        if (DX) da[ks][t2] = *reinterpret_cast<const bf16x8*>(dyimg + off);
+                    }
+            };
+            auto load_t = [&](int rp) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int off = tr_row + ct * (2 * RP * 16) + (2 * rp) * 256;
+                    tT[ct] = bw_join(bw_tr(timg + off), bw_tr(timg + off + 256));
+                }
+            };
+            load_w(0); load_a(0); load_t(0);
+            float dbsum[HT] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 2 * HT; ++st) {
+                const int rp = st / HT, ht = st % HT;
+                const float bias = s_b1[48 * wave + 16 * ht + li];
                 f32x4 hacc[2], gacc[2];
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) { hacc[t2] = f32x4{bias, bias, bias, bias}; gacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -223,14 +252,15 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
-                        const int off = rd_row + ks * (4 * RP * 16) + (2 * rp + t2) * 256;
-                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(ximg + off);
-                        hacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, w1f[ks], hacc[t2], 0, 0, 0);
-                        if (DX) {
-                            const bf16x8 df = *reinterpret_cast<const bf16x8*>(dyimg + off);
-                            gacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, w2f[ks], gacc[t2], 0, 0, 0);
-                        }
+                        hacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[ks][t2], w1f[ks], hacc[t2], 0, 0, 0);
+                        if (DX) gacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[ks][t2], w2f[ks], gacc[t2], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < 2 * HT) {
+                    load_w((st + 1) % HT);
+                    if (W2 && ht == HT - 1) load_a(rp + 1);      // launch 1 keeps the row fragments of an rp for its three steps
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 // GELU (launch 1) / GELU' (launch 2) in place: lane = hidden unit 48 w + 16 ht + li, rows 16 (2 rp + t2) + 4 lg + e
                 unsigned op[4];
 #pragma unroll
@@ -239,32 +269,38 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (W2) v[e] = gelu_bf16(hacc[t2][e]);
-                        else { v[e] = gacc[t2][e] * gelu_bf16_grad(hacc[t2][e]); dbsum += v[e]; }
+                        else { v[e] = gacc[t2][e] * gelu_bf16_grad(hacc[t2][e]); dbsum[ht] += v[e]; }
                     }
                     op[2 * t2] = pack2bf(v[0], v[1]); op[2 * t2 + 1] = pack2bf(v[2], v[3]);
                     if (DX) *reinterpret_cast<uint2*>(dhimg + dh_wr + ((2 * rp + t2) * 4 * NP1 + 16 * ht) * 8) = make_uint2(op[2 * t2], op[2 * t2 + 1]);
                 }
                 const bf16x8 of = __builtin_bit_cast(bf16x8, (u32x4_t{op[0], op[1], op[2], op[3]}));       // g (launch 1) / dh (launch 2)
+                __builtin_amdgcn_sched_barrier(0);
+                // launch 2 (12 row fragments = 48 registers): re-requested for every step, AFTER the GELU block whose temporaries they
+                // would not fit beside, in flight under the six weight-gradient products
+                if (DX && st + 1 < 2 * HT) load_a((st + 1) / HT);
                 // weight gradient: k = the 32 rows of this pair of row tiles (slot 8 lg + j: j < 4 row 4 lg + j, else 16 + 4 lg + j - 4)
-                const char* timg = W2 ? dyimg : ximg;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const int off = tr_row + ct * (2 * RP * 16) + (2 * rp) * 256;
-                    const bf16x8 tT = bw_join(bw_tr(timg + off), bw_tr(timg + off + 256));
-                    if (W2) {          // D[c][hidden] += dy^T[c][row] g[row][hidden]
-                        wacc[ht][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT, of, wacc[ht][ct], 0, 0, 0);
-                        if (ht == 0) {          // bias gradient of the second linear: column sums of dy; wave w < 6 keeps columns 16 w ..
-                            float sy = 0.f;
+                    if (W2) wacc[ht][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[ct], of, wacc[ht][ct], 0, 0, 0);     // D[c][hidden]
+                    else wacc[ht][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, tT[ct], wacc[ht][ct], 0, 0, 0);        // D[hidden][c]
+                }
+                if (W2 && ht == 0) {          // bias gradient of the second linear: column sums of dy; wave w < 6 keeps columns 16 w ..
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) sy += bf2f((bf16_t)tT[e]);
-                            bacc[0] += (ct == wave) ? sy : 0.f;
-                        }
-                    } else {           // D[hidden][c] += dh^T[hidden][row] xhat[row][c]
-                        wacc[ht][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, tT, wacc[ht][ct], 0, 0, 0);
+                    for (int ct = 0; ct < CT; ++ct) {
+                        float sy = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sy += bf2f((bf16_t)tT[ct][e]);
+                        bacc[0] += (ct == wave) ? sy : 0.f;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ht == HT - 1 && rp == 0) load_t(1);
             }
-            if (DX) bacc[ht] += dbsum;
+            if (DX) {
+#pragma unroll
+                for (int ht = 0; ht < HT; ++ht) bacc[ht] += dbsum[ht];
+            }
         }
         bw_barrier();                                                                                    // B: images consumed (launch 2: the dh image is complete)
         if (DX) {
@@ -273,15 +309,31 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
             f32x4 lacc[CT / 2];
 #pragma unroll
             for (int c3 = 0; c3 < CT / 2; ++c3) lacc[c3] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-            for (int ks = 0; ks < H4 / 32; ++ks) {
-                const char* pa = dhimg + dh_rd + rt * (4 * NP1 * 8) + ks * (32 * 8);
-                const bf16x8 af = bw_join(bw_tr(pa), bw_tr(pa + 16 * 8));
+            {
+                const char* pa0 = dhimg + dh_rd + rt * (4 * NP1 * 8);
+                const char* pb0 = w1img + w1_rd + (3 * ch) * (2 * NP1 * 16);
+                bf16x8 af = bw_join(bw_tr(pa0), bw_tr(pa0 + 16 * 8));
+                bf16x8 bf[CT / 2];
 #pragma unroll
-                for (int c3 = 0; c3 < CT / 2; ++c3) {
-                    const char* pb = w1img + w1_rd + (3 * ch + c3) * (2 * NP1 * 16) + ks * (32 * 16);
-                    const bf16x8 bf = bw_join(bw_tr(pb), bw_tr(pb + 16 * 16));
-                    lacc[c3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, lacc[c3], 0, 0, 0);
+                for (int c3 = 0; c3 < CT / 2; ++c3) bf[c3] = bw_join(bw_tr(pb0 + c3 * (2 * NP1 * 16)), bw_tr(pb0 + c3 * (2 * NP1 * 16) + 16 * 16));
+#pragma unroll
+                for (int ks = 0; ks < H4 / 32; ++ks) {
+                    const bf16x8 ac = af;
+                    bf16x8 bc[CT / 2];
+#pragma unroll
+                    for (int c3 = 0; c3 < CT / 2; ++c3) bc[c3] = bf[c3];
+                    if (ks + 1 < H4 / 32) {               // next k-step's fragments are in flight under this step's products
+                        const char* pa = pa0 + (ks + 1) * (32 * 8);
+                        af = bw_join(bw_tr(pa), bw_tr(pa + 16 * 8));
+#pragma unroll
+                        for (int c3 = 0; c3 < CT / 2; ++c3) {
+                            const char* pb = pb0 + c3 * (2 * NP1 * 16) + (ks + 1) * (32 * 16);
+                            bf[c3] = bw_join(bw_tr(pb), bw_tr(pb + 16 * 16));
+                        }
+                    }
+#pragma unroll
+                    for (int c3 = 0; c3 < CT / 2; ++c3) lacc[c3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac, bc[c3], lacc[c3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
