@@ -81,6 +81,23 @@ __device__ __forceinline__ float bw_sum8(float v) {        // sum over the 8 lan
     return v;
 }
 
+#ifdef BW_PROBE
+// Debug builds only (tools/bwdw_probe.py): shader-clock totals per phase, summed over waves; [mode][16]
+//   0 tile loop  1 P0  2 wait A  3 P1 products  4 P1 loads issue  5 P1 GELU  6 P1 weight-gradient  7 wait B  8 P2  9 wait C1+C2  10 P3  11 waves
+__device__ unsigned long long g_bw_probe[2][16];
+MMG_API int mmg_debug_bwdw_probe(unsigned long long* out32, int reset) {
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_bw_probe), 256) != hipSuccess) return 1;
+    unsigned long long z[32] = {0};
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_bw_probe), z, 256) != hipSuccess) return 1;
+    return 0;
+}
+#define BWP_T(var) const long long var = __builtin_readcyclecounter()
+#define BWP_ADD(idx, a, b) pr[idx] += (b) - (a)
+#else
+#define BWP_T(var)
+#define BWP_ADD(idx, a, b)
+#endif
+
 // MODE 1 ("cnblock_bwdw_w2_kernel"):  h = xhat (W1 gamma)^T + b1', g = GELU(h), dW2raw += dy^T g, db2raw += colsum(dy)
 // MODE 2 ("cnblock_bwdw_dx_kernel"):  h, dG = dy (gamma_ls W2), dh = dG GELU'(h), dW1 += un-folded dh^T xhat, db1 += colsum(dh),
 //                                     d LN-out = dh W1, LayerNorm backward -> dd, ln_dw, ln_db
@@ -118,14 +135,22 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
         for (int i = tid; i < C; i += BW_THREADS) s_lnw[i] = a.ln_w[i];
         for (int i = tid; i < H4; i += BW_THREADS) s_b1[i] = a.b1f[i];
     }
-    const bf16_t* w1g = a.packed + Cfg::PK_W1IMG + (long)wave * HT * KS * 512;        // this wave's fragments (512 bf16 each)
-    const bf16_t* w2g = w1g + Cfg::PK_FRAGS;
+    // Global operands go through buffer instructions: descriptor + uniform offset in scalar registers, one 32-bit lane offset - no
+    // 64-bit per-lane addresses (round 3, first version: hipcc kept 18 of them, spilled to scratch, and re-loaded each behind a
+    // `s_waitcnt vmcnt(0)`: 19 % of the second launch).  Byte offsets stay below 2^32 (checked by the entry point).
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, (int)(Cfg::PK_TOTAL * 2), 0x27000);
+    const int w1g = (int)(Cfg::PK_W1IMG * 2) + wave * (HT * KS * 1024);               // this wave's fragments (1 KiB each)
+    const int w2g = w1g + (int)(Cfg::PK_FRAGS * 2);
+    // staging role of this wave: waves 0-3 bring 16 rows of d each (LayerNorm statistics, 4 lanes per row), waves 4-7 the same rows of dy
+    const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dd, 0, (int)(unsigned)(a.M * C * 2), 0x27000);
+    const bool st_dy = wave >= 4;
+    const __amdgpu_buffer_rsrc_t rs_row = __builtin_amdgcn_make_buffer_rsrc((void*)(st_dy ? a.dy : a.xd), 0, (int)(unsigned)(a.M * C * 2), 0x27000);
 
     // ---- per-lane addresses -----------------------------------------------------------------------------------------------------
     // staging (P0): lanes 0-31 take d, lanes 32-63 take dy; 8 rows per wave, 4 lanes per row, 3 pieces of 16 bytes per lane
-    const int st_half = lane >> 5, st_row = 8 * wave + (lane & 7), st_lg = (lane >> 3) & 3;
+    const int st_row = 16 * (wave & 3) + li, st_lg = lg;
     const int st_lds = ((st_lg * RP) + 16 * (st_row >> 4) + bw_pos(st_row & 15)) * 16;         // + ks * 4 * RP * 16
-    const bf16_t* st_src = (st_half ? a.dy : a.xd) + (long)st_row * C + 8 * st_lg;             // + tile * R * C + 32 * ks
+    const int st_off = (st_row * C + 8 * st_lg) * 2;                                           // bytes; + tile * R * C * 2 (scalar) + 64 * ks
     // row-wise operand fragment (A of the C-deep products): row 16 rt + li, 16-byte column 4 ks + lg
     const int rd_row = (lg * RP + bw_pos(li)) * 16;                                            // + ks * 4 * RP * 16 + rt * 256
     // transposed reads of a row image: rows 4 lg + q of a 16-row tile, column piece p of a 16-column tile
@@ -146,18 +171,23 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
 
     bw_barrier();
 
-    uint4 pre[KS];
+    u32x4_t pre[KS];
     if ((int)blockIdx.x < a.ntiles) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) pre[ks] = *reinterpret_cast<const uint4*>(st_src + (long)blockIdx.x * R * C + 32 * ks);
+        for (int ks = 0; ks < KS; ++ks) pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off + 64 * ks, (int)blockIdx.x * (R * C * 2), 0);
     }
 
+#ifdef BW_PROBE
+    long long pr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    BWP_T(pr_loop0);
     int parity = 0;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
+        BWP_T(pr_p0);
         // ================= P0: rows -> LDS images (xhat, dy), row statistics =======================================================
         {
-            char* img = st_half ? dyimg : ximg;
-            if (st_half == 0) {
+            char* img = st_dy ? dyimg : ximg;
+            if (!st_dy) {
                 // (three passes over the 12 packed registers instead of 24 unpacked floats)
                 float s = 0.f;
 #pragma unroll
@@ -166,7 +196,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
 #pragma unroll
                     for (int e = 0; e < 4; ++e) s += bf2f_lo(w[e]) + bf2f_hi(w[e]);
                 }
-                s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
                 const float mean = s * (1.0f / C);
                 float qq = 0.f;
 #pragma unroll
@@ -175,7 +205,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float d0 = bf2f_lo(w[e]) - mean, d1 = bf2f_hi(w[e]) - mean; qq = fmaf(d0, d0, qq); qq = fmaf(d1, d1, qq); }
                 }
-                qq += __shfl_xor(qq, 8, 64); qq += __shfl_xor(qq, 16, 64);
+                qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
                 const float rstd = rsqrtf(qq * (1.0f / C) + a.eps);
                 if (DX && st_lg == 0) { s_stat[(parity * R + st_row) * 2] = mean; s_stat[(parity * R + st_row) * 2 + 1] = rstd; }
 #pragma unroll
@@ -188,15 +218,18 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                 }
             } else {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<uint4*>(img + st_lds + ks * (4 * RP * 16)) = pre[ks];
+                for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<u32x4_t*>(img + st_lds + ks * (4 * RP * 16)) = pre[ks];
             }
         }
+        BWP_T(pr_a0);
         bw_barrier();                                                                                    // A
+        BWP_T(pr_a1);
+        BWP_ADD(1, pr_p0, pr_a0); BWP_ADD(2, pr_a0, pr_a1);
         // next tile's rows: requested now, consumed at its P0
         if (tile + (int)gridDim.x < a.ntiles) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                pre[ks] = *reinterpret_cast<const uint4*>(st_src + (long)(tile + gridDim.x) * R * C + 32 * ks);
+                pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off + 64 * ks, (tile + (int)gridDim.x) * (R * C * 2), 0);
         }
 
         // ================= P1: this wave's 48 hidden units over the 64 rows ==========================================================
@@ -214,12 +247,8 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
             auto load_w = [&](int ht) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const uint4 u1 = *reinterpret_cast<const uint4*>(w1g + ((ht * KS + ks) * 64 + lane) * 8);
-                    w1f[ks] = __builtin_bit_cast(bf16x8, (u32x4_t{u1.x, u1.y, u1.z, u1.w}));
-                    if (DX) {
-                        const uint4 u2 = *reinterpret_cast<const uint4*>(w2g + ((ht * KS + ks) * 64 + lane) * 8);
-                        w2f[ks] = __builtin_bit_cast(bf16x8, (u32x4_t{u2.x, u2.y, u2.z, u2.w}));
-                    }
+                    w1f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, w1g + (ht * KS + ks) * 1024, 0));
+                    if (DX) w2f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, w2g + (ht * KS + ks) * 1024, 0));
                 }
             };
             auto load_a = [&](int rp) {
@@ -246,6 +275,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                 const int rp = st / HT, ht = st % HT;
                 const float bias = s_b1[48 * wave + 16 * ht + li];
                 f32x4 hacc[2], gacc[2];
+                BWP_T(pr_s0);
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) { hacc[t2] = f32x4{bias, bias, bias, bias}; gacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
@@ -256,11 +286,13 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                         if (DX) gacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[ks][t2], w2f[ks], gacc[t2], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
+                BWP_T(pr_s1);
                 if (st + 1 < 2 * HT) {
                     load_w((st + 1) % HT);
                     if (W2 && ht == HT - 1) load_a(rp + 1);      // launch 1 keeps the row fragments of an rp for its three steps
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                BWP_T(pr_s2);
                 // GELU (launch 1) / GELU' (launch 2) in place: lane = hidden unit 48 w + 16 ht + li, rows 16 (2 rp + t2) + 4 lg + e
                 unsigned op[4];
 #pragma unroll
@@ -278,6 +310,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                 __builtin_amdgcn_sched_barrier(0);
                 // launch 2 (12 row fragments = 48 registers): re-requested for every step, AFTER the GELU block whose temporaries they
                 // would not fit beside, in flight under the six weight-gradient products
+                BWP_T(pr_s3);
                 if (DX && st + 1 < 2 * HT) load_a((st + 1) / HT);
                 // weight gradient: k = the 32 rows of this pair of row tiles (slot 8 lg + j: j < 4 row 4 lg + j, else 16 + 4 lg + j - 4)
 #pragma unroll
@@ -296,13 +329,18 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ht == HT - 1 && rp == 0) load_t(1);
+                BWP_T(pr_s4);
+                BWP_ADD(3, pr_s0, pr_s1); BWP_ADD(4, pr_s1, pr_s2); BWP_ADD(5, pr_s2, pr_s3); BWP_ADD(6, pr_s3, pr_s4);
             }
             if (DX) {
 #pragma unroll
                 for (int ht = 0; ht < HT; ++ht) bacc[ht] += dbsum[ht];
             }
         }
+        BWP_T(pr_b0);
         bw_barrier();                                                                                    // B: images consumed (launch 2: the dh image is complete)
+        BWP_T(pr_b1);
+        BWP_ADD(7, pr_b0, pr_b1);
         if (DX) {
             // ================= P2: d LN-out = dh W1 for (row tile rt, 3 column tiles), gamma / beta gradients ========================
             const int rt = wave >> 1, ch = wave & 1;
@@ -344,27 +382,36 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                 for (int e = 0; e < 4; ++e) { sb += lacc[c3][e]; sg = fmaf(lacc[c3][e], bf2f((bf16_t)xh[e]), sg); }
                 dgacc[c3] += sg; dbacc[c3] += sb;
             }
+            BWP_T(pr_c0);
+            // P3's operands that live in the row images: this thread's 16 xhat values (row tid >> 3, columns 16 (tid & 7) ..), read now -
+            // the next tile's P0 may overwrite the images as soon as the last wave has passed C2
+            const int p3_row = tid >> 3, p3_part = (tid & 7) < CT ? (tid & 7) : 0;
+            const u32x4_t xq0 = *reinterpret_cast<const u32x4_t*>(ximg + ((2 * p3_part) * RP + 16 * (p3_row >> 4) + bw_pos(p3_row & 15)) * 16);
+            const u32x4_t xq1 = *reinterpret_cast<const u32x4_t*>(ximg + ((2 * p3_part + 1) * RP + 16 * (p3_row >> 4) + bw_pos(p3_row & 15)) * 16);
             bw_barrier();                                                                                // C1: dh image has been read
+            BWP_T(pr_c1);
 #pragma unroll
             for (int c3 = 0; c3 < CT / 2; ++c3)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s_dln[(16 * rt + 4 * lg + e) * C + 16 * (3 * ch + c3) + li] = lacc[c3][e];
+            BWP_T(pr_c2);
             bw_barrier();                                                                                // C2
+            BWP_T(pr_c3);
+            BWP_ADD(8, pr_b1, pr_c0); BWP_ADD(9, pr_c0, pr_c1); BWP_ADD(9, pr_c2, pr_c3);
 
             // ================= P3: LayerNorm backward, one row per 8 lanes (6 of them active, 16 columns each) =======================
-            const int row = tid >> 3, part = tid & 7;
+            const int row = p3_row, part = tid & 7;
             const bool act = part < CT;
             const int c0 = act ? 16 * part : 0;
-            const long grow = (long)tile * R + row;
-            const float mean = s_stat[(parity * R + row) * 2], rstd = s_stat[(parity * R + row) * 2 + 1];
+            const float rstd = s_stat[(parity * R + row) * 2 + 1];
             float x[16];
             float s1 = 0.f, s2 = 0.f;
-            if (act) {
-                const uint4 d0 = *reinterpret_cast<const uint4*>(a.xd + grow * C + c0);
-                const uint4 d1 = *reinterpret_cast<const uint4*>(a.xd + grow * C + c0 + 8);
-                const unsigned w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            {
+                const unsigned w[8] = {xq0.x, xq0.y, xq0.z, xq0.w, xq1.x, xq1.y, xq1.z, xq1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { x[2 * e] = (bf2f_lo(w[e]) - mean) * rstd; x[2 * e + 1] = (bf2f_hi(w[e]) - mean) * rstd; }
+                for (int e = 0; e < 8; ++e) { x[2 * e] = bf2f_lo(w[e]); x[2 * e + 1] = bf2f_hi(w[e]); }
+            }
+            if (act) {
 #pragma unroll
                 for (int v4 = 0; v4 < 4; ++v4) {
                     const f32x4 dl = *reinterpret_cast<const f32x4*>(s_dln + row * C + c0 + 4 * v4);
@@ -388,13 +435,23 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                         for (int e = 0; e < 4; ++e) r4[e] = rstd * (fmaf(-x[8 * h8 + 4 * v4 + e], m2, dl[e] * gm[e]) - m1);
                         o[2 * v4] = pack2bf(r4[0], r4[1]); o[2 * v4 + 1] = pack2bf(r4[2], r4[3]);
                     }
-                    *reinterpret_cast<uint4*>(a.dd + grow * C + c0 + 8 * h8) = make_uint4(o[0], o[1], o[2], o[3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, rs_dd, (row * C + c0 + 8 * h8) * 2, tile * (R * C * 2), 0);
                 }
             }
             // (no barrier: the next P0 writes the row images and the other parity of s_stat; s_dln is rewritten as the dh image only
             //  after the next tile's barrier A, which every wave reaches after its P3)
+            BWP_T(pr_p3);
+            BWP_ADD(10, pr_c3, pr_p3);
         }
     }
+#ifdef BW_PROBE
+    {
+        BWP_T(pr_loop1);
+        pr[0] = pr_loop1 - pr_loop0; pr[11] = 1;
+        if (lane == 0)
+            for (int i = 0; i < 12; ++i) atomicAdd(&g_bw_probe[MODE - 1][i], (unsigned long long)pr[i]);
+    }
+#endif
 
     // ================= epilogue: the accumulators leave as fp32 atomics =================================================================
     bw_barrier();
@@ -505,6 +562,7 @@ MMG_API int mmg_cnblock_bwdw(const void* dy, const void* xd, const float* ln_w, 
                              float* ln_db, long long M, int C, hipStream_t stream) {
     MMG_CHECK_ARG(C == 96, "mmg_cnblock_bwdw: C=%d is not supported (96)", C);
     MMG_CHECK_ARG(M > 0 && M % BwCfg<96>::R == 0, "mmg_cnblock_bwdw: M=%lld must be a positive multiple of %d", M, BwCfg<96>::R);
+    MMG_CHECK_ARG(M * 96 * 2 < (1LL << 32), "mmg_cnblock_bwdw: M=%lld rows exceed the 4 GiB buffer range of one launch", M);
     MMG_CHECK_ARG(dy && xd && ln_w && ln_b && packed && b1f && dd && dW1 && db1 && dW2raw && db2raw && ln_dw && ln_db,
                   "mmg_cnblock_bwdw: null pointer");
     BwArgs a;

@@ -214,7 +214,7 @@ def cnblock_mlp_bwd(dy, xd, ln_w, ln_b, eps, packed_bwd, b1, hpre=None, ln_grads
 
 def cnblock_bwdw_supported(C, M):
     """On-chip weight-gradient backward of the CNBlock MLP (csrc/cnblock_bwdw.hip): C = 96, M a multiple of 64."""
-    return bool(_hip.load().mmg_cnblock_bwdw_supported(C)) and M % 64 == 0
+    return bool(_hip.load().mmg_cnblock_bwdw_supported(C)) and M % 64 == 0 and M * C * 2 < 2 ** 32
 
 
 def cnblock_bwdw_pack(w1, w2, ln_w, ln_b, layer_scale, b1):
