@@ -114,6 +114,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1img = smem + Cfg::OFF_W1;
+    // launch 1 double-buffers the two row images (it has the LDS: no W1 / dh image), which leaves ONE barrier per tile; launch 2 has one set
     char* ximg = smem + Cfg::OFF_X;
     char* dyimg = smem + Cfg::OFF_DY;
     char* dhimg = smem + Cfg::OFF_DH;
@@ -181,9 +182,43 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
     long long pr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     BWP_T(pr_loop0);
+    bf16x8 w1f[KS], w2f[DX ? KS : 1];
+    bf16x8 xa[KS][2], da[DX ? KS : 1][2];
+    bf16x8 tT[CT];
+    const char* timg = W2 ? dyimg : ximg;           // (re-pointed per tile in launch 1)
+    auto load_w = [&](int ht) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            w1f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, w1g + (ht * KS + ks) * 1024, 0));
+            if (DX) w2f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, w2g + (ht * KS + ks) * 1024, 0));
+        }
+    };
+    auto load_a = [&](int rp) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int off = rd_row + ks * (4 * RP * 16) + (2 * rp + t2) * 256;
+                xa[ks][t2] = *reinterpret_cast<const bf16x8*>(ximg + off);
+                if (DX) da[ks][t2] = *reinterpret_cast<const bf16x8*>(dyimg + off);
+            }
+    };
+    auto load_t = [&](int rp) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int off = tr_row + ct * (2 * RP * 16) + (2 * rp) * 256;
+            tT[ct] = bw_join(bw_tr(timg + off), bw_tr(timg + off + 256));
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) load_w(0);        // (the weight fragments of step 0: requested one tile ahead from here on)
     int parity = 0;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
         BWP_T(pr_p0);
+        if (W2) {                 // this tile's image pair
+            ximg = smem + Cfg::OFF_X + parity * (2 * Cfg::ROWIMG);
+            dyimg = ximg + Cfg::ROWIMG;
+            timg = dyimg;
+        }
         // ================= P0: rows -> LDS images (xhat, dy), row statistics =======================================================
         {
             char* img = st_dy ? dyimg : ximg;
@@ -240,35 +275,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
         //   transposed fragments (k = rows)            once per rp, loaded after the last weight-gradient product of the previous rp
         //   weight fragments of the next step          requested from L2 right after this step's products, landing under the GELU block
         {
-            bf16x8 w1f[KS], w2f[DX ? KS : 1];
-            bf16x8 xa[KS][2], da[DX ? KS : 1][2];
-            bf16x8 tT[CT];
-            const char* timg = W2 ? dyimg : ximg;
-            auto load_w = [&](int ht) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    w1f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, w1g + (ht * KS + ks) * 1024, 0));
-                    if (DX) w2f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, w2g + (ht * KS + ks) * 1024, 0));
-                }
-            };
-            auto load_a = [&](int rp) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int t2 = 0; t2 < 2; ++t2) {
-                        const int off = rd_row + ks * (4 * RP * 16) + (2 * rp + t2) * 256;
-                        xa[ks][t2] = *reinterpret_cast<const bf16x8*>(ximg + off);
-                        if (DX) da[ks][t2] = *reinterpret_cast<const bf16x8*>(dyimg + off);
-                    }
-            };
-            auto load_t = [&](int rp) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const int off = tr_row + ct * (2 * RP * 16) + (2 * rp) * 256;
-                    tT[ct] = bw_join(bw_tr(timg + off), bw_tr(timg + off + 256));
-                }
-            };
-            load_w(0); load_a(0); load_t(0);
+            load_a(0); load_t(0);
             float dbsum[HT] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 2 * HT; ++st) {
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                 f32x4 hacc[2], gacc[2];
                 BWP_T(pr_s0);
 #pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) { hacc[t2] = f32x4{bias, bias, bias, bias}; gacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int t2 = 0; t2 < 2; ++t2) { hacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; gacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -287,7 +294,9 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 BWP_T(pr_s1);
-                if (st + 1 < 2 * HT) {
+                if (st + 1 == 2 * HT) {
+                    if (tile + (int)gridDim.x < a.ntiles) load_w(0);      // next tile's first step: in flight over P2 / P3 / P0
+                } else {
                     load_w((st + 1) % HT);
                     if (W2 && ht == HT - 1) load_a(rp + 1);      // launch 1 keeps the row fragments of an rp for its three steps
                 }
@@ -300,8 +309,8 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (W2) v[e] = gelu_bf16(hacc[t2][e]);
-                        else { v[e] = gacc[t2][e] * gelu_bf16_grad(hacc[t2][e]); dbsum[ht] += v[e]; }
+                        if (W2) v[e] = gelu_bf16(hacc[t2][e] + bias);
+                        else { v[e] = gacc[t2][e] * gelu_bf16_grad(hacc[t2][e] + bias); dbsum[ht] += v[e]; }
                     }
                     op[2 * t2] = pack2bf(v[0], v[1]); op[2 * t2 + 1] = pack2bf(v[2], v[3]);
                     if (DX) *reinterpret_cast<uint2*>(dhimg + dh_wr + ((2 * rp + t2) * 4 * NP1 + 16 * ht) * 8) = make_uint2(op[2 * t2], op[2 * t2 + 1]);
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
             }
         }
         BWP_T(pr_b0);
-        bw_barrier();                                                                                    // B: images consumed (launch 2: the dh image is complete)
+        if (DX) bw_barrier();                                                                            // B: the dh image is complete (launch 1: nothing to wait for - the next tile stages into the other image pair)
         BWP_T(pr_b1);
         BWP_ADD(7, pr_b0, pr_b1);
         if (DX) {
