@@ -137,7 +137,7 @@ int mmg_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const fl
 
 /* y = GELU(x) elementwise, bf16, n % 8 == 0 (rebuilds the FFN activation in the backward pass). */
 int mmg_gelu_fwd_bf16(const void* x, void* y, long long n, mmg_stream_t stream);
-/* out = dy * act'(pre) elementwise, bf16; kind 0 = GELU(erf), 1 = ReLU; n % 8 == 0. */
+/* out = dy * act'(pre) elementwise, bf16; kind 0 = GELU(erf), 1 = ReLU, 2 = GELU(erf) by the exp-free polynomial of mmg_cnblock_bwdw; n % 8 == 0. */
 int mmg_act_grad_bf16(const void* dy, const void* pre, void* out, long long n, int kind, mmg_stream_t stream);
 /* dtype conversions of flat buffers */
 int mmg_cast_f32_bf16(const float* x, void* y, long long n, mmg_stream_t stream);

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (W2) v[e] = gelu_bf16(hacc[t2][e] + bias);
-                        else { v[e] = gacc[t2][e] * gelu_bf16_grad(hacc[t2][e] + bias); dbsum[ht] += v[e]; }
+                        else { v[e] = gacc[t2][e] * gelu_bf16_grad_poly(hacc[t2][e] + bias); dbsum[ht] += v[e]; }
                     }
                     op[2 * t2] = pack2bf(v[0], v[1]); op[2 * t2 + 1] = pack2bf(v[2], v[3]);
                     if (DX) *reinterpret_cast<uint2*>(dhimg + dh_wr + ((2 * rp + t2) * 4 * NP1 + 16 * ht) * 8) = make_uint2(op[2 * t2], op[2 * t2 + 1]);

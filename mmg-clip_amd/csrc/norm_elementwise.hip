@@ -677,7 +677,8 @@ MMG_API int mmg_dropout_bwd(const float* dy, const void* keep, float* dx, long l
     return 0;
 }
 
-// out = dy * act'(pre) elementwise (bf16), kind 0 = GELU(erf), 1 = ReLU; n % 8 == 0
+// out = dy * act'(pre) elementwise (bf16), kind 0 = GELU(erf), 1 = ReLU, 2 = GELU(erf) by the exp-free polynomial of the on-chip
+// weight-gradient backward (common.h: gelu_bf16_grad_poly; here for its all-bf16-inputs test); n % 8 == 0
 __global__ __launch_bounds__(256) void act_grad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ pre,
                                                        bf16_t* __restrict__ out, size_t nvec, int kind) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
@@ -685,12 +686,12 @@ __global__ __launch_bounds__(256) void act_grad_kernel(const bf16_t* __restrict_
         unpack8(reinterpret_cast<const uint4*>(dy)[i], g);
         unpack8(reinterpret_cast<const uint4*>(pre)[i], h);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = kind == 0 ? g[e] * gelu_bf16_grad(h[e]) : (h[e] > 0.f ? g[e] : 0.f);
+        for (int e = 0; e < 8; ++e) g[e] = kind == 0 ? g[e] * gelu_bf16_grad(h[e]) : (kind == 2 ? g[e] * gelu_bf16_grad_poly(h[e]) : (h[e] > 0.f ? g[e] : 0.f));
         reinterpret_cast<uint4*>(out)[i] = pack8(g);
     }
 }
 MMG_API int mmg_act_grad_bf16(const void* dy, const void* pre, void* out, long long n, int kind, hipStream_t stream) {
-    MMG_CHECK_ARG(dy && pre && out && n > 0 && n % 8 == 0 && (kind == 0 || kind == 1), "mmg_act_grad_bf16: bad argument");
+    MMG_CHECK_ARG(dy && pre && out && n > 0 && n % 8 == 0 && (kind >= 0 && kind <= 2), "mmg_act_grad_bf16: bad argument");
     const size_t nvec = (size_t)n / 8;
     int blocks = (int)((nvec + 255) / 256 > 8192 ? 8192 : (nvec + 255) / 256);
     hipLaunchKernelGGL(act_grad_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)pre, (bf16_t*)out, nvec, kind);

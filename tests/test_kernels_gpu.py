@@ -489,3 +489,8 @@ def test_polynomial_gelu_over_every_bf16_input(dev):
     g = g.float().cpu().double()
     dref = 0.5 * (1 + torch.erf(xd / math.sqrt(2))) + xd * torch.exp(-0.5 * xd * xd) / math.sqrt(2 * math.pi)
     assert ((g - dref).abs() <= 2 ** -8 * dref.abs() + 5.5e-4).all()
+    # the exp-free derivative polynomial of the on-chip weight-gradient backward (kind 2): the same bar; exactly 0 / 1 beyond the clamp
+    call("mmg_act_grad_bf16", ptr(torch.ones_like(x)), ptr(x), ptr(g := torch.empty_like(x)), x.numel(), 2, stream())
+    g = g.float().cpu().double()
+    assert ((g - dref).abs() <= 2 ** -8 * dref.abs() + 5.5e-4).all()
+    assert (g[xd >= 4] == 1).all() and (g[xd <= -4] == 0).all()
