@@ -341,6 +341,11 @@ def main():
                 r = linalg.PROFILE.roofline(name, st)
                 r["ms_per_step"] = round(st["total_ms"] / args.profile_steps, 3)
                 key = name if name in traffic else r["family"]
+                if "*" in name:          # one entry point = several kernels per call (cnblock_bwdw): the sum of their per-launch bytes
+                    parts = [v for k, v in tj.get("kernels", {}).items() if k.startswith(name.split("<")[0] + "<") and "pack" not in k]
+                    if parts:
+                        traffic[name] = {"hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] for v in parts)}
+                        key = name
                 if key in traffic:
                     r["traffic"] = round(traffic[key]["hbm_bytes_per_launch"])
                     r["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)" + ("" if key == name else f", mean over {key}")

@@ -29,13 +29,10 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define BW_THREADS 512
 
 template <int C> struct BwCfg {
     static constexpr int H4 = 4 * C;               // hidden width
     static constexpr int R = 64;                   // rows per tile
-    static constexpr int HS = H4 / 8;              // hidden units per wave (48)
-    static constexpr int HT = HS / 16;             // 16-unit tiles per wave (3)
     static constexpr int KS = C / 32;              // k-steps of the C-deep products (3)
     static constexpr int CT = C / 16;              // 16-column tiles of a C-wide result (6)
     static constexpr int KG = C / 8;               // 16-byte columns of a row image (12)
@@ -49,7 +46,7 @@ template <int C> struct BwCfg {
     static constexpr int LDS = OFF_STAT + 2 * R * 2 * 4;
     // packed weight buffer (bf16 elements): [W1 LDS image][W1 gamma fragments][gamma_ls W2^T fragments]
     static constexpr long PK_W1IMG = (long)KG * NP1 * 8;
-    static constexpr long PK_FRAGS = (long)8 * HT * KS * 64 * 8;
+    static constexpr long PK_FRAGS = (long)(H4 / 16) * KS * 64 * 8;
     static constexpr long PK_TOTAL = PK_W1IMG + 2 * PK_FRAGS;
     static_assert(R * C * 4 <= DHIMG, "the fp32 d LN-out tile aliases the dh image");
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -106,10 +103,14 @@ MMG_API int mmg_debug_bwdw_probe(unsigned long long* out32, int reset) {
 // registers to scratch in every arrangement tried - AGPR-pinned accumulators included, which the compiler splits 128 / 128), and one
 // wave per SIMD halves the VALU issue rate this GELU-bound kernel lives on.  The split costs one more h product (6 instead of 5
 // GEMM-equivalents per block) and no extra GELU work: GELU runs in launch 1, GELU' in launch 2.
-template <int C, int MODE>
-__global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArgs a) {
+// NW = waves per workgroup: 8 (two per SIMD, 256 registers each) or 12 (three per SIMD, 168 registers: launch 1, whose register
+// needs allow it - a third wave per SIMD to fill the other two's waits).  A wave owns H4 / NW hidden units.
+template <int C, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwArgs a) {
     typedef BwCfg<C> Cfg;
-    constexpr int H4 = Cfg::H4, HT = Cfg::HT, KS = Cfg::KS, CT = Cfg::CT, RP = Cfg::RP, NP1 = Cfg::NP1, R = Cfg::R;
+    constexpr int H4 = Cfg::H4, KS = Cfg::KS, CT = Cfg::CT, RP = Cfg::RP, NP1 = Cfg::NP1, R = Cfg::R;
+    constexpr int BW_THREADS = NW * 64, HS = H4 / NW, HT = HS / 16;
+    static_assert(HS % 16 == 0 && (MODE == 1 || NW == 8), "hidden slice of a wave: whole 16-unit tiles; launch 2 is laid out for 8 waves");
     constexpr bool W2 = MODE == 1, DX = MODE == 2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
     const int w2g = w1g + (int)(Cfg::PK_FRAGS * 2);
     // staging role of this wave: waves 0-3 bring 16 rows of d each (LayerNorm statistics, 4 lanes per row), waves 4-7 the same rows of dy
     const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dd, 0, (int)(unsigned)(a.M * C * 2), 0x27000);
-    const bool st_dy = wave >= 4;
+    const bool st_dy = (wave & 4) != 0, st_on = wave < 8;          // (waves 8 .. of a 12-wave workgroup do not stage)
     const __amdgpu_buffer_rsrc_t rs_row = __builtin_amdgcn_make_buffer_rsrc((void*)(st_dy ? a.dy : a.xd), 0, (int)(unsigned)(a.M * C * 2), 0x27000);
 
     // ---- per-lane addresses -----------------------------------------------------------------------------------------------------
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
     // transposed reads of a row image: rows 4 lg + q of a 16-row tile, column piece p of a 16-column tile
     const int tr_row = ((p >> 1) * RP + bw_pos(4 * lg + q)) * 16 + (p & 1) * 8;               // + ct * 2 * RP * 16 + rt * 256
     // dh image: write 8 bytes = rows 4 lg .. +3 of hidden unit (own) ; transposed read: hidden 4 lg + q (+16), row piece p
-    const int dh_wr = (lg * NP1 + 48 * wave + li) * 8;                                          // + (rt * 4 * NP1 + 16 * ht) * 8
+    const int dh_wr = (lg * NP1 + HS * wave + li) * 8;                                          // + (rt * 4 * NP1 + 16 * ht) * 8
     const int dh_rd = (p * NP1 + 4 * lg + q) * 8;                                               // + rt * 4 * NP1 * 8 + (32 ks [+16]) * 8
     // W1 image, transposed: hidden 4 lg + q (+16), column piece p of column tile ct
     const int w1_rd = ((p >> 1) * NP1 + 4 * lg + q) * 16 + (p & 1) * 8;                       // + ct * 2 * NP1 * 16 + (32 ks [+16]) * 16
@@ -167,13 +168,13 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
     for (int i = 0; i < HT; ++i)
 #pragma unroll
         for (int j = 0; j < CT; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bacc[HT] = {0.f, 0.f, 0.f};          // MODE 1: [0] = column sums of dy (wave w < 6: columns 16 w ..); MODE 2: db1 of the 3 hidden tiles
+    float bacc[3] = {0.f, 0.f, 0.f};          // MODE 1: [0] = column sums of dy (wave w < 6: columns 16 w ..); MODE 2: db1 of the 3 hidden tiles
     float dgacc[CT / 2] = {0.f, 0.f, 0.f}, dbacc[CT / 2] = {0.f, 0.f, 0.f};
 
     bw_barrier();
 
     u32x4_t pre[KS];
-    if ((int)blockIdx.x < a.ntiles) {
+    if (st_on && (int)blockIdx.x < a.ntiles) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off + 64 * ks, (int)blockIdx.x * (R * C * 2), 0);
     }
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
         // ================= P0: rows -> LDS images (xhat, dy), row statistics =======================================================
         {
             char* img = st_dy ? dyimg : ximg;
-            if (!st_dy) {
+            if (!st_on) {
+            } else if (!st_dy) {
                 // (three passes over the 12 packed registers instead of 24 unpacked floats)
                 float s = 0.f;
 #pragma unroll
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
         BWP_T(pr_a1);
         BWP_ADD(1, pr_p0, pr_a0); BWP_ADD(2, pr_a0, pr_a1);
         // next tile's rows: requested now, consumed at its P0
-        if (tile + (int)gridDim.x < a.ntiles) {
+        if (st_on && tile + (int)gridDim.x < a.ntiles) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off + 64 * ks, (tile + (int)gridDim.x) * (R * C * 2), 0);
@@ -276,11 +278,11 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
         //   weight fragments of the next step          requested from L2 right after this step's products, landing under the GELU block
         {
             load_a(0); load_t(0);
-            float dbsum[HT] = {0.f, 0.f, 0.f};
+            float dbsum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 2 * HT; ++st) {
                 const int rp = st / HT, ht = st % HT;
-                const float bias = s_b1[48 * wave + 16 * ht + li];
+                const float bias = s_b1[HS * wave + 16 * ht + li];
                 f32x4 hacc[2], gacc[2];
                 BWP_T(pr_s0);
 #pragma unroll
@@ -476,13 +478,13 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)       // dW2raw[c = 16 ct + 4 lg + e][hidden 48 w + 16 ht + li]
-                    atomicAdd(a.dW2raw + (long)(16 * ct + 4 * lg + e) * H4 + 48 * wave + 16 * ht + li, wacc[ht][ct][e]);
+                    atomicAdd(a.dW2raw + (long)(16 * ct + 4 * lg + e) * H4 + HS * wave + 16 * ht + li, wacc[ht][ct][e]);
     } else {
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht) {
             float v = bacc[ht];
             v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            if (lg == 0) { s_b1[48 * wave + 16 * ht + li] = v; atomicAdd(a.db1 + 48 * wave + 16 * ht + li, v); }
+            if (lg == 0) { s_b1[HS * wave + 16 * ht + li] = v; atomicAdd(a.db1 + HS * wave + 16 * ht + li, v); }
         }
         const int ch = wave & 1;
 #pragma unroll
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void cnblock_bwdw_kernel(const BwArg
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // dW1[hidden 48 w + 16 ht + 4 lg + e][c] = gamma[c] (dh^T xhat) + beta[c] db1[hidden]   (un-folding of the LayerNorm affine)
-                    const int n = 48 * wave + 16 * ht + 4 * lg + e;
+                    const int n = HS * wave + 16 * ht + 4 * lg + e;
                     atomicAdd(a.dW1 + (long)n * C + c, fmaf(gm, wacc[ht][ct][e], bt * s_b1[n]));
                 }
             }
@@ -515,7 +517,7 @@ struct BwPack { const float* w1; const float* w2; const float* ln_w; const float
 template <int C>
 __global__ __launch_bounds__(256) void cnblock_bwdw_pack_kernel(const BwPack a) {
     typedef BwCfg<C> Cfg;
-    constexpr int H4 = Cfg::H4, NP1 = Cfg::NP1, KS = Cfg::KS, HT = Cfg::HT;
+    constexpr int H4 = Cfg::H4, NP1 = Cfg::NP1, KS = Cfg::KS;
     const long total = Cfg::PK_TOTAL;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + H4; e += (long)gridDim.x * blockDim.x) {
         if (e >= total) {                         // b1' = b1 + W1 beta
@@ -529,13 +531,12 @@ __global__ __launch_bounds__(256) void cnblock_bwdw_pack_kernel(const BwPack a) 
         if (e < Cfg::PK_W1IMG) {                  // [16-byte column kg][hidden, pitch NP1][8]: plain W1 (the d LN-out product)
             const int kg = (int)(e / (NP1 * 8)), n = (int)((e / 8) % NP1), j = (int)(e % 8);
             v = n < H4 ? a.w1[(long)n * C + 8 * kg + j] : 0.f;
-        } else {                                  // fragments: [which][wave][ht][ks][lane][8]: B[k = c = 32 ks + 8 lg + j][hidden 48 w + 16 ht + li]
+        } else {                                  // fragments: [which][16-unit hidden tile][ks][lane][8]: B[k = c = 32 ks + 8 lg + j][hidden 48 w + 16 ht + li]
             long f = e - Cfg::PK_W1IMG;
             const int which = (int)(f / Cfg::PK_FRAGS);
             f -= (long)which * Cfg::PK_FRAGS;
-            const int j = (int)(f % 8), lane = (int)((f / 8) % 64), ks = (int)((f / 512) % KS), ht = (int)((f / (512 * KS)) % HT);
-            const int w = (int)(f / (512 * KS * HT));
-            const int n = 48 * w + 16 * ht + (lane & 15), c = 32 * ks + 8 * (lane >> 4) + j;
+            const int j = (int)(f % 8), lane = (int)((f / 8) % 64), ks = (int)((f / 512) % KS), tile16 = (int)(f / (512 * KS));
+            const int n = 16 * tile16 + (lane & 15), c = 32 * ks + 8 * (lane >> 4) + j;    // (wave w of an NW-wave launch owns tiles w H4/(16 NW) ..)
             v = which == 0 ? a.w1[(long)n * C + c] * a.ln_w[c]                 // W1 gamma_ln  (LayerNorm affine folded)
                            : a.w2[(long)c * H4 + n] * a.ls[c];                 // gamma_ls W2^T (layer scale folded: dG = dy (gamma W2))
         }
@@ -581,11 +582,14 @@ MMG_API int mmg_cnblock_bwdw(const void* dy, const void* xd, const float* ln_w, 
     a.M = M; a.ntiles = (int)(M / BwCfg<96>::R);
     const int cap = bw_cu_count();
     const int grid = a.ntiles < cap ? a.ntiles : cap;
-    mmg_allow_lds(cnblock_bwdw_kernel<96, 1>, BwCfg<96>::LDS);
-    mmg_allow_lds(cnblock_bwdw_kernel<96, 2>, BwCfg<96>::LDS);
+    static const int w12 = getenv("MMG_BWDW_W12") ? atoi(getenv("MMG_BWDW_W12")) : 1;      // launch 1 with 12 waves (A/B knob)
+    mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 8>, BwCfg<96>::LDS);
+    mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 12>, BwCfg<96>::LDS);
+    mmg_allow_lds(cnblock_bwdw_kernel<96, 2, 8>, BwCfg<96>::LDS);
     MMG_NOTE_KERNEL("cnblock_bwdw_kernel<96, *>");
-    hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1>), dim3(grid), dim3(BW_THREADS), BwCfg<96>::LDS, stream, a);
-    hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 2>), dim3(grid), dim3(BW_THREADS), BwCfg<96>::LDS, stream, a);
+    if (w12) hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 12>), dim3(grid), dim3(768), BwCfg<96>::LDS, stream, a);
+    else hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 8>), dim3(grid), dim3(512), BwCfg<96>::LDS, stream, a);
+    hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 2, 8>), dim3(grid), dim3(512), BwCfg<96>::LDS, stream, a);
     MMG_LAUNCH_CHECK("mmg_cnblock_bwdw");
     return 0;
 }

@@ -24,16 +24,37 @@ md = [f"# {tag} — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-c
 for r in rows[:24]:
     md.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.1f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
 md += ["", f"Sum of kernel time {tot/1e6:.0f} ms over {steps} steps = {tot/1e6/steps:.0f} ms/step vs {b['ms_per_step']:.0f} ms/step wall under the profiler.", ""]
+def norm(name):            # "void gemm_nt_kernel<256, 256, 64, 4, 2, 0>(GemmNT)" -> "gemm_nt_kernel<256, 256, 64, 4, 2, 0>"
+    name = name.replace("void ", "")
+    depth, cut = 0, len(name)
+    for i, ch in enumerate(name):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            cut = i
+            break
+    return name[:cut].strip()
+md += ["## bench.py's HIP-event figures (its extra one-stream steps) beside this trace, kernel by kernel", "",
+       "| kernel (bench line) | bench launches / step | bench avg us | rocprof avg us | bench / rocprof |", "|---|---|---|---|---|"]
+worst = 0.0
 for rl in [b["roofline"]] + b.get("roofline_other_kernels", []):
-    fam = rl["kernel"]
-    # (the weight-gradient family is two kernels: gemm_tn_kernel and the wide-tile gemm_tn_wide_kernel; bench.py times both as one)
-    base = lambda n: {"gemm_tn_wide_kernel": "gemm_tn_kernel"}.get(n, n)
-    sel = [r for r in rows if base(r["Name"].replace("void ", "").split("<")[0].split("(")[0].strip()) == fam]
-    if not sel:
+    name = rl["kernel"]
+    if "*" in name:            # one entry point, several launches (cnblock_bwdw: two kernels per call): sum of their averages
+        pre = name.split("<")[0]
+        sel = [r for r in rows if norm(r["Name"]).startswith(pre + "<") and "pack" not in r["Name"]]
+        avg = sum(float(r["TotalDurationNs"]) / int(r["Calls"]) for r in sel) / 1e3 if sel else 0.0
+    else:
+        sel = [r for r in rows if norm(r["Name"]) == name] or [r for r in rows if norm(r["Name"]).split("<")[0] == name]
+        n = sum(int(r["Calls"]) for r in sel)
+        avg = sum(float(r["TotalDurationNs"]) for r in sel) / 1e3 / n if n else 0.0
+    if not avg:
         continue
-    n = sum(int(r["Calls"]) for r in sel); t = sum(float(r["TotalDurationNs"]) for r in sel)
-    md.append(f"`{fam}` (all instantiations, all {steps} steps): {n} launches, {t/1e6:.1f} ms, average {t/1e3/n:.1f} us per launch "
-              f"(bench.py's HIP-event figure for the {b['steps']} timed steps of the same run: {rl['launches']} launches, {rl['avg_launch_us']} us average).")
+    ratio = rl["avg_launch_us"] / avg
+    if rl["ms_per_step"] >= 1.0:
+        worst = max(worst, abs(ratio - 1.0))
+    md.append(f"| `{name}` | {rl['launches'] / b['roofline_method']['profiled_steps']:.0f} | {rl['avg_launch_us']:.1f} | {avg:.1f} | {ratio:.3f} |")
+md += ["", f"Largest deviation among kernels with >= 1 ms per step: {100 * worst:.1f} %.  Sum of the bench line's instrumented kernels: "
+       f"{b['roofline_method']['instrumented_kernel_ms_per_step']} ms per step (one stream) against {b['ms_per_step']} ms per step of the timed region.", ""]
 open(f"{out}/{tag}_bench_default.md", "w").write("\n".join(md) + "\n")
 print(md[-1])
 PY

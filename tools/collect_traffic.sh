@@ -21,7 +21,15 @@ for tag, d in (("FETCH_SIZE", "/tmp/pmc_f"), ("WRITE_SIZE", "/tmp/pmc_w")):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == tag:
-            k = r["Kernel_Name"].split("(")[0].strip()
+            k = r["Kernel_Name"].replace("void ", "")
+            depth = 0
+            for i, ch in enumerate(k):          # cut the argument list, not the template arguments
+                depth += ch == "<"
+                depth -= ch == ">"
+                if ch == "(" and depth == 0:
+                    k = k[:i]
+                    break
+            k = k.strip()
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])     # KiB
     res[tag] = agg
@@ -31,8 +39,8 @@ for k, (n, kb) in res["FETCH_SIZE"].items():
     kernels[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * kb * 1024 / n, "write_bytes_per_launch": w[1] * 1024 / max(w[0], 1)}
 fam = collections.defaultdict(lambda: [0, 0.0])        # kernel family = symbol name without template arguments
 for k, v in kernels.items():
-    f = k.replace("void ", "").split("<")[0].strip()
-    f = {"gemm_tn_wide_kernel": "gemm_tn_kernel"}.get(f, f)        # one family for bench.py: both weight-gradient kernels
+    v["hbm_bytes_per_launch"] = v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]
+    f = k.split("<")[0].strip()
     fam[f][0] += v["launches"]
     fam[f][1] += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
 families = {f: {"launches": n, "hbm_bytes_per_launch": tot / n} for f, (n, tot) in fam.items() if n}
@@ -40,5 +48,5 @@ summary = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes)
            "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE x1, KiB -> bytes",
            "families": families, "kernels": kernels}
 json.dump(summary, open(out + "/traffic.json", "w"), indent=1)
-print(json.dumps({f: families[f] for f in ("gemm_nt_kernel", "gemm_tn_kernel", "cnblock_mlp_fwd_kernel", "cnblock_mlp_bwd_kernel") if f in families}))
+print(json.dumps({f: families[f] for f in ("gemm_nt_kernel", "gemm_tn_wide_kernel", "cnblock_mlp_fwd_kernel", "cnblock_bwdw_kernel") if f in families}))
 PY
