@@ -582,7 +582,9 @@ MMG_API int mmg_cnblock_bwdw(const void* dy, const void* xd, const float* ln_w, 
     a.M = M; a.ntiles = (int)(M / BwCfg<96>::R);
     const int cap = bw_cu_count();
     const int grid = a.ntiles < cap ? a.ntiles : cap;
-    static const int w12 = getenv("MMG_BWDW_W12") ? atoi(getenv("MMG_BWDW_W12")) : 1;      // launch 1 with 12 waves (A/B knob)
+    // launch 1 with 12 waves (three per SIMD, 168 registers): same-box A/B at 16.8 M rows, two runs each: 13.10 / 13.15 ms against
+    // 12.94 / 13.09 with 8 waves - the launch is bound by VALU issue (GELU), not by latency, so the third wave buys nothing.  Off.
+    static const int w12 = getenv("MMG_BWDW_W12") ? atoi(getenv("MMG_BWDW_W12")) : 0;
     mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 8>, BwCfg<96>::LDS);
     mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 12>, BwCfg<96>::LDS);
     mmg_allow_lds(cnblock_bwdw_kernel<96, 2, 8>, BwCfg<96>::LDS);
