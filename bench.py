@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="ConvNeXt blocks with C >= 512: forward pointwise GEMMs on e4m3 MFMA (config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="text tower on the caller's stream in EVERY step (what the roofline leg's extra steps always do): the setting the "
+                         "rocprofv3 kernel trace under profiles/ is collected with, so that its per-kernel averages are the kernels' own")
     ap.add_argument("--profile-steps", type=int, default=2,
                     help="instrumented steps run AFTER the timed region for the roofline leg (one stream, HIP events per launch)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -225,6 +228,8 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg, model, criterion, arenas = build(args, comm)
+    if args.one_stream:
+        model.text_stream_enabled = False
     batch = synthetic_batch(args.batch, S=args.seq_len, image_size=None if args.variant == "faithful" else args.image_size, seed=42 + rank)
     key = "image_features" if args.variant == "faithful" else "image"
     batch[key] = batch[key].to(dev)
@@ -297,7 +302,7 @@ def main():
         barrier()
         profile_ms = (time.perf_counter() - t1) / args.profile_steps * 1000.0
         linalg.PROFILE.disable()
-        model.text_stream_enabled = True
+        model.text_stream_enabled = not args.one_stream
 
     ms_per_step = elapsed / args.steps * 1000.0
     pairs = args.batch * world * args.steps
@@ -315,6 +320,7 @@ def main():
                                 f"{'ViT-B/16' if args.variant == 'vit_b16' else 'ConvNeXt-' + args.variant} {args.image_size}x{args.image_size}x1 + BERT-base "
                                 f"S={args.seq_len}, LinearProjection 768->512, CLIPLoss, AdamW, all parameters trained"),
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "micro_batch": args.micro_batch,
+                   "streams": "one (--one-stream)" if args.one_stream else "text tower on a side stream",
                    "parallelism": f"dp{world}", "loss_scope": "global (all-gather)" if world > 1 else "local",
                    "algorithmic_gflop_per_pair": gflop,
                    "model_tflops_per_gpu": round(value * gflop / 1000.0 / world, 1) if gflop else None,

@@ -234,6 +234,7 @@ static int launch_ln(const LNArgs& a, hipStream_t stream) {
     const size_t shm = BWD ? 2 * a.C * sizeof(float) : 0;
 #define LN_LAUNCH(GG, CC)                                                                                       \
     do {                                                                                                        \
+        MMG_NOTE_KERNEL(BWD ? "layernorm_bwd_kernel<%d, %d>" : "layernorm_fwd_kernel<%d, %d>", GG, CC);         \
         if (BWD) hipLaunchKernelGGL((layernorm_bwd_kernel<GG, CC>), dim3(blocks), dim3(256), shm, stream, a);  \
         else hipLaunchKernelGGL((layernorm_fwd_kernel<GG, CC>), dim3(blocks), dim3(256), 0, stream, a);        \
     } while (0)

@@ -1,13 +1,16 @@
 #!/bin/bash
 # Per-kernel time of the default bench command — run on the GPU box:  bash tools/collect_profile.sh gpurun_out/prof rNN
 # Writes $1/${2}_bench_default_kernel_stats.csv and $1/${2}_bench_default.md (copy both to profiles/).
+# The traced command is `bench.py --no-cpu-baseline --one-stream`: with the text tower on its side stream (the default of the timed
+# region) the trace stretches BERT's small kernels, which then run beside the image tower's full-grid ones - a kernel's OWN duration,
+# which is what bench.py's roofline leg reports from its extra one-stream steps, needs one stream.  `$3` = extra bench flags.
 set -e
 OUT=${1:-gpurun_out/prof}; TAG=${2:-r01}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 "$REPO/bench.py" --no-cpu-baseline > "$OUT/${TAG}_profiled_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 "$REPO/bench.py" --no-cpu-baseline --one-stream $3 > "$OUT/${TAG}_profiled_bench.log" 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -17,8 +20,8 @@ open(f"{out}/{tag}_bench_default_kernel_stats.csv", "w").write(open(f).read())
 line = [l for l in open(f"{out}/{tag}_profiled_bench.log") if l.startswith("{")][-1]
 b = json.loads(line)
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-steps = b["steps"] + b["warmup"]
-md = [f"# {tag} — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (1x MI355X, {b['config']['workload']}, {b['warmup']} warm-up + {b['steps']} timed steps)", "",
+steps = b["steps"] + b["warmup"] + (b["roofline_method"]["profiled_steps"] + 1 if "roofline_method" in b else 0)
+md = [f"# {tag} — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --one-stream` (1x MI355X, {b['config']['workload']}, {b['warmup']} warm-up + {b['steps']} timed steps)", "",
       f"Full per-kernel table: `{tag}_bench_default_kernel_stats.csv`; bench line of the profiled run: {b['value']:.1f} {b['unit']}, {b['ms_per_step']:.1f} ms/step.", "",
       "| kernel | calls | total ms | avg us | % of GPU time |", "|---|---|---|---|---|"]
 for r in rows[:24]:

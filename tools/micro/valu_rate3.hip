@@ -48,6 +48,11 @@ template <int V> __device__ __forceinline__ void op(float& x, float& y, f32x2& p
     if constexpr (V == 39) asm volatile("v_cmp_gt_f32 vcc, %1, %0" : : "v"(x), "v"(a) : "vcc");
     if constexpr (V == 40) asm volatile("v_cmp_gt_f32_e64 %2, %1, %0\n v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(a), "s"(msk));
     if constexpr (V == 31) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(a));
+    // round 3: two bf16 multiply-adds per lane and instruction (depthwise 7x7 on pixel pairs?)
+    if constexpr (V == 41) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+    if constexpr (V == 42) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x) : "v"(y), "v"(b));
+    if constexpr (V == 43) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b));
+    if constexpr (V == 44) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(x) : "v"(a));
 }
 
 template <int V>
@@ -96,5 +101,6 @@ int main() {
     row<8>("v_pk_fma_f32"); row<36>("v_pk_fma_f32 op_sel_hi (v only)"); row<32>("v_pk_fma_f32 p,p,s,q"); row<33>("v_pk_fma_f32 p,p,q,s"); row<34>("v_pk_mul_f32 p,p,s"); row<35>("v_fma_f32 x,x,v,s"); row<9>("v_pk_mul_f32"); row<28>("v_pk_add_f32"); row<23>("v_pk_fma_f16"); row<24>("v_pk_mul_f16");
     row<10>("v_and_b32 x,x,v"); row<12>("v_and_b32 x,literal,x"); row<11>("v_lshlrev_b32 x,16,x"); row<20>("v_perm_b32"); row<21>("v_add_u32 x,x,v");
     row<22>("v_mov_b32"); row<31>("v_cndmask_b32 x,x,v,vcc"); row<37>("v_cndmask_b32_e64 x,x,v,s[pair]"); row<39>("v_cmp_gt_f32 vcc"); row<38>("v_cmp vcc + v_cndmask vcc (pair)"); row<40>("v_cmp_e64 s + v_cndmask_e64 s (pair)"); row<13>("v_cvt_pk_bf16_f32"); row<19>("v_rcp_f32"); row<30>("v_exp_f32");
+    row<41>("v_dot2c_f32_bf16 x,v,v"); row<42>("v_dot2c_f32_bf16 x,y,v"); row<43>("v_dot2_f32_bf16 x,v,v,x"); row<44>("v_alignbit_b32 x,x,v,16");
     return 0;
 }
