@@ -40,8 +40,10 @@ def layernorm_fwd_f32(x, gamma, beta, eps, want_stats=True, want_f32=False, res=
     yf = torch.empty(M, C, device=x.device, dtype=torch.float32) if want_f32 else None
     mean = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(M, device=x.device, dtype=torch.float32) if want_stats else None
-    call("mmg_layernorm_fwd_f32", ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(gamma), ptr(beta),
-         float(eps), ptr(y), y.stride(0), ptr(yf), C if want_f32 else 0, ptr(mean), ptr(rstd), M, C, stream())
+    PROFILE.timed("layernorm_fwd_kernel", 8.0 * M * C, (6 + (4 if want_f32 else 0) + (8 if res is not None else 0)) * M * C,
+                  lambda: call("mmg_layernorm_fwd_f32", ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(gamma),
+                               ptr(beta), float(eps), ptr(y), y.stride(0), ptr(yf), C if want_f32 else 0, ptr(mean), ptr(rstd), M, C, stream()),
+                  f"fp32 rows M={M} C={C}" + (" +res" if res is not None else ""))
     return y, yf, mean, rstd
 
 
@@ -49,8 +51,10 @@ def layernorm_bwd_f32(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, add=Non
     M, C = x.shape
     assert x.dtype == torch.float32
     dx = torch.empty(M, C, device=x.device, dtype=BF16)
-    call("mmg_layernorm_bwd_f32", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
-         dx.stride(0), ptr(dgamma), ptr(dbeta), M, C, ptr(add), add.stride(0) if add is not None else 0, stream())
+    PROFILE.timed("layernorm_bwd_kernel", 16.0 * M * C, (8 + (2 if add is not None else 0)) * M * C,
+                  lambda: call("mmg_layernorm_bwd_f32", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+                               dx.stride(0), ptr(dgamma), ptr(dbeta), M, C, ptr(add), add.stride(0) if add is not None else 0, stream()),
+                  f"fp32 rows M={M} C={C}" + (" +add" if add is not None else ""))
     return dx
 
 
