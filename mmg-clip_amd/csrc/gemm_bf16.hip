@@ -125,8 +125,13 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
                 // the activation itself (needed by the weight-gradient GEMM of the same layer) shares cdf/pdf with
                 // its derivative: emitting it here replaces a separate read-modify-write pass over the [M,N] tensor
                 float a0, d0, a1, d1;
+#ifdef NT_DGELU_POLY        // A/B build (tools/nt_dgelu_tiles.py): two independent exp-free polynomials instead of the shared rcp / exp form
+                a0 = gelu_bf16(h0); d0 = gelu_bf16_grad_poly(h0);
+                a1 = gelu_bf16(h1); d1 = gelu_bf16_grad_poly(h1);
+#else
                 gelu_both(h0, a0, d0);
                 gelu_both(h1, a1, d1);
+#endif
                 v[2 * e] *= d0;
                 v[2 * e + 1] *= d1;
                 act[e] = pack2bf(a0, a1);

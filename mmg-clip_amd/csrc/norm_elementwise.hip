@@ -9,6 +9,7 @@
 //   input scaling x*65535, (x-32767.5)/32767.5               (mmgclip/networks/image_features.py:95-99)
 //   torch.optim.AdamW                                        (mmgclip/experiments/ClassifierExperiment.py:74,118)
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dim C of a bf16 [M,C] matrix.  A row is owned by a group of G lanes
@@ -226,7 +227,13 @@ static int launch_ln(const LNArgs& a, hipStream_t stream) {
     const int nch = a.C / 8;
     int G = 8;
     while (G < nch && G < 64) G <<= 1;
-    const int ch = cdiv(nch, G);
+    int ch = cdiv(nch, G);
+    // round 3: widths of 3 x 2^k chunks (192, 384, 768, 1536: every ConvNeXt-T / BERT width but 96) take G = 2^k lanes x 3 chunks per row
+    // instead of the next power of two with a quarter of the lanes idle: no idle lanes, 64 / G rows and three times the bytes in flight
+    // per wave (the kernels are latency-bound: 0.46 of HBM peak before).  MMG_LN_CH3=0: the round-2 selection (A/B).
+    static const int ch3_on = getenv("MMG_LN_CH3") ? atoi(getenv("MMG_LN_CH3")) : 1;
+    const bool ch3 = ch3_on && nch % 3 == 0 && (nch / 3 == 8 || nch / 3 == 16 || nch / 3 == 32 || nch / 3 == 64);
+    if (ch3) { G = nch / 3; ch = 3; }
     const int rows_per_block = 4 * (64 / G);
     int blocks = cdiv(a.M, rows_per_block);
     const int cap = BWD ? 1024 : 4096;
@@ -238,7 +245,11 @@ static int launch_ln(const LNArgs& a, hipStream_t stream) {
         if (BWD) hipLaunchKernelGGL((layernorm_bwd_kernel<GG, CC>), dim3(blocks), dim3(256), shm, stream, a);  \
         else hipLaunchKernelGGL((layernorm_fwd_kernel<GG, CC>), dim3(blocks), dim3(256), 0, stream, a);        \
     } while (0)
-    if (G == 8) LN_LAUNCH(8, 1);
+    if (ch3 && G == 8) LN_LAUNCH(8, 3);
+    else if (ch3 && G == 16) LN_LAUNCH(16, 3);
+    else if (ch3 && G == 32) LN_LAUNCH(32, 3);
+    else if (ch3) LN_LAUNCH(64, 3);
+    else if (G == 8) LN_LAUNCH(8, 1);
     else if (G == 16) LN_LAUNCH(16, 1);
     else if (G == 32) LN_LAUNCH(32, 1);
     else if (ch <= 1) LN_LAUNCH(64, 1);

@@ -28,6 +28,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             us = s.elapsed_time(e) * 200
             print(f"  NT M={M} N={N} K={K} {mode:9s} {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
 else:
-    for knobs in ({}, {"MMG_GEMM_256": "0"}, {"MMG_GEMM_256": "0", "MMG_GEMM_KBIG": "128"}, {}):
+    sets = [{}, {"MMG_GEMM_256": "0"}, {"MMG_GEMM_256": "0", "MMG_GEMM_KBIG": "128"}, {}]
+    poly = os.path.join(ROOT, "tools", "libmmg_ab_ntpoly.so")     # A/B build: -DNT_DGELU_POLY (two exp-free polynomials in the GELU' epilogue)
+    if os.path.isfile(poly):
+        sets = [{}, {"MMGCLIP_HIP_LIB": poly}, {}, {"MMGCLIP_HIP_LIB": poly}] if "--poly" in sys.argv else sets
+    for knobs in sets:
         print("==", knobs or "default", flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env={**os.environ, **knobs})
