@@ -362,7 +362,14 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
                 if (ok && want_aux) as_v[hp] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
             }
         }
+        // LDS ordering is all the two slab barriers need: a __syncthreads() also waits for every outstanding global access (vmcnt(0) -
+        // on CDNA4 that counter includes STORES), i.e. for the previous slab's 16-byte output stores and for this slab's own epilogue
+        // reads issued just above - one exposed store / load latency per slab (round 3, MMG_NT_EPI_SYNC A/B build)
+#ifdef NT_EPI_SYNCTHREADS
         __syncthreads();   // fragment reads (q = 0) / the previous slab's reads are done
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         if (wm == q) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -370,7 +377,11 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
                 for (int j = 0; j < NI; ++j)
                     *reinterpret_cast<f32x4*>(Cs + (i * 16 + li) * LDCS + wn * (BN / 2) + j * 16 + 4 * lg) = acc[i][j];
         }
+#ifdef NT_EPI_SYNCTHREADS
         __syncthreads();
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         if (col_ok) {
 #pragma unroll
             for (int hp = 0; hp < QP; ++hp) {

@@ -228,11 +228,13 @@ static int launch_ln(const LNArgs& a, hipStream_t stream) {
     int G = 8;
     while (G < nch && G < 64) G <<= 1;
     int ch = cdiv(nch, G);
-    // round 3: widths of 3 x 2^k chunks (192, 384, 768, 1536: every ConvNeXt-T / BERT width but 96) take G = 2^k lanes x 3 chunks per row
-    // instead of the next power of two with a quarter of the lanes idle: no idle lanes, 64 / G rows and three times the bytes in flight
-    // per wave (the kernels are latency-bound: 0.46 of HBM peak before).  MMG_LN_CH3=0: the round-2 selection (A/B).
+    // round 3, FORWARD only: widths of 3 x 2^k chunks (192, 384, 768, 1536: every ConvNeXt-T / BERT width but 96) take G = 2^k lanes x 3
+    // chunks per row instead of the next power of two with a quarter of the lanes idle: no idle lanes, 64 / G rows and three times the bytes
+    // in flight per wave.  Same-run A/B (tools/ln_ab.py, profiles/r03_ln_ab.txt): forward 498 -> 389 us at M = 1 M x 384 (3.2 -> 4.1 TB/s),
+    // 213 -> 191 at 262 k x 768, 779 -> 745 at 4.2 M x 192; the BACKWARD got slower with it (652 -> 805, 1231 -> 1523, 321 -> 432 us: three
+    // chunks of dgamma / dbeta accumulators and operands per lane) and keeps the round-2 selection.  MMG_LN_CH3=0: off (A/B).
     static const int ch3_on = getenv("MMG_LN_CH3") ? atoi(getenv("MMG_LN_CH3")) : 1;
-    const bool ch3 = ch3_on && nch % 3 == 0 && (nch / 3 == 8 || nch / 3 == 16 || nch / 3 == 32 || nch / 3 == 64);
+    const bool ch3 = !BWD && ch3_on && nch % 3 == 0 && (nch / 3 == 8 || nch / 3 == 16 || nch / 3 == 32 || nch / 3 == 64);
     if (ch3) { G = nch / 3; ch = 3; }
     const int rows_per_block = 4 * (64 / G);
     int blocks = cdiv(a.M, rows_per_block);
