@@ -59,10 +59,18 @@ __device__ __forceinline__ size_t ln_out_offset(const LNArgs& a, int m, int ld) 
     return prow * ld + ((h & 1) * 2 + (w & 1)) * a.C;
 }
 
+// sum over the G lanes of a group (G = 4 ... 64, groups aligned to G), every lane gets the total.  Inside a DPP row of 16 lanes the
+// butterfly runs on DPP modifiers (quad_perm, row_half_mirror, row_mirror: plain VALU operations); hipcc lowers every __shfl_xor to
+// ds_bpermute_b32 - an LDS-pipe round trip with an exposed lgkmcnt wait each, 12 of them in a row-sized dependent chain per LayerNorm
+// row at G = 64 (round 3: the reason these kernels sat at 0.46 of HBM peak).  Only the 16 / 32 steps still cross rows by ds_bpermute.
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (G >= 2) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    if (G >= 4) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    if (G >= 8) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    if (G >= 16) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
