@@ -48,7 +48,8 @@ template <int C> struct BwCfg {
     static constexpr long PK_W1IMG = (long)KG * NP1 * 8;
     static constexpr long PK_FRAGS = (long)(H4 / 16) * KS * 64 * 8;
     static constexpr long PK_TOTAL = PK_W1IMG + 2 * PK_FRAGS;
-    static_assert(R * C * 4 <= DHIMG, "the fp32 d LN-out tile aliases the dh image");
+    static constexpr int DLP = C + 4;              // pitch (floats) of the fp32 d LN-out tile: +4 makes the LayerNorm-backward row reads conflict-free
+    static_assert(R * DLP * 4 <= DHIMG, "the fp32 d LN-out tile aliases the dh image");
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
     char* ximg = smem + Cfg::OFF_X;
     char* dyimg = smem + Cfg::OFF_DY;
     char* dhimg = smem + Cfg::OFF_DH;
-    float* s_dln = reinterpret_cast<float*>(smem + Cfg::OFF_DH);           // [R][C] fp32, aliases the dh image between barriers
+    float* s_dln = reinterpret_cast<float*>(smem + Cfg::OFF_DH);           // [R][DLP] fp32 (times gamma), aliases the dh image between barriers
     float* s_lnw = reinterpret_cast<float*>(smem + Cfg::OFF_LNW);
     float* s_b1 = reinterpret_cast<float*>(smem + Cfg::OFF_B1);            // b1' = b1 + W1 beta; reused for the db1 exchange at the end
     float* s_stat = reinterpret_cast<float*>(smem + Cfg::OFF_STAT);        // [parity][R][mean, rstd]
@@ -402,9 +403,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
             bw_barrier();                                                                                // C1: dh image has been read
             BWP_T(pr_c1);
 #pragma unroll
-            for (int c3 = 0; c3 < CT / 2; ++c3)
+            for (int c3 = 0; c3 < CT / 2; ++c3) {
+                const float gm = s_lnw[16 * (3 * ch + c3) + li];          // d xhat = d LN-out * gamma: folded here, the row phase reads no gamma
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s_dln[(16 * rt + 4 * lg + e) * C + 16 * (3 * ch + c3) + li] = lacc[c3][e];
+                for (int e = 0; e < 4; ++e) s_dln[(16 * rt + 4 * lg + e) * Cfg::DLP + 16 * (3 * ch + c3) + li] = lacc[c3][e] * gm;
+            }
             BWP_T(pr_c2);
             bw_barrier();                                                                                // C2
             BWP_T(pr_c3);
@@ -415,37 +418,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
             const bool act = part < CT;
             const int c0 = act ? 16 * part : 0;
             const float rstd = s_stat[(parity * R + row) * 2 + 1];
-            float x[16];
+            float x[16], gv[16];
             float s1 = 0.f, s2 = 0.f;
             {
                 const unsigned w[8] = {xq0.x, xq0.y, xq0.z, xq0.w, xq1.x, xq1.y, xq1.z, xq1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { x[2 * e] = bf2f_lo(w[e]); x[2 * e + 1] = bf2f_hi(w[e]); }
             }
-            if (act) {
 #pragma unroll
-                for (int v4 = 0; v4 < 4; ++v4) {
-                    const f32x4 dl = *reinterpret_cast<const f32x4*>(s_dln + row * C + c0 + 4 * v4);
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + c0 + 4 * v4);
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(s_dln + row * Cfg::DLP + c0 + 4 * v4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float g = dl[e] * gm[e]; s1 += g; s2 = fmaf(g, x[4 * v4 + e], s2); }
-                }
+                for (int e = 0; e < 4; ++e) { gv[4 * v4 + e] = dl[e]; s1 += dl[e]; s2 = fmaf(dl[e], x[4 * v4 + e], s2); }
             }
+            if (!act) { s1 = 0.f; s2 = 0.f; }
             s1 = bw_sum8(s1); s2 = bw_sum8(s2);
             if (act) {
                 const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
 #pragma unroll
-                for (int h8 = 0; h8 < 2; ++h8) {          // second pass over the LDS tile: 8 columns per 16-byte store
+                for (int h8 = 0; h8 < 2; ++h8) {
                     unsigned o[4];
 #pragma unroll
-                    for (int v4 = 0; v4 < 2; ++v4) {
-                        const f32x4 dl = *reinterpret_cast<const f32x4*>(s_dln + row * C + c0 + 8 * h8 + 4 * v4);
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + c0 + 8 * h8 + 4 * v4);
-                        float r4[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) r4[e] = rstd * (fmaf(-x[8 * h8 + 4 * v4 + e], m2, dl[e] * gm[e]) - m1);
-                        o[2 * v4] = pack2bf(r4[0], r4[1]); o[2 * v4 + 1] = pack2bf(r4[2], r4[3]);
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = pack2bf(rstd * (fmaf(-x[8 * h8 + 2 * e], m2, gv[8 * h8 + 2 * e]) - m1), rstd * (fmaf(-x[8 * h8 + 2 * e + 1], m2, gv[8 * h8 + 2 * e + 1]) - m1));
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, rs_dd, (row * C + c0 + 8 * h8) * 2, tile * (R * C * 2), 0);
                 }
             }
