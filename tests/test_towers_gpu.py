@@ -66,6 +66,30 @@ def test_convnext_tower_forward_backward(dev, size, n, variant):
     assert not bad, f"{len(bad)} of {len(worst)} gradients off: {list(bad.items())[:8]}"
 
 
+def test_convnext_stage1_on_chip_weight_gradient_backward_equals_the_gemm_path(dev, monkeypatch):
+    """Round 3: the stage-1 blocks' backward runs on mmg_cnblock_bwdw (weight gradients accumulated on chip).  The same tower with
+    MMG_BWDW=0 takes the round-2 path (fused data-path kernel + two weight-gradient GEMMs); every parameter gradient of the two runs must
+    agree to bf16 rounding noise (training sizes always qualify: H, W multiples of 32 make the stage-1 row count a multiple of 64)."""
+    from mmgclip.networks.encoder import ConvNextTinyEncoder
+    img = torch.rand(3, 1, 96, 64, generator=torch.Generator().manual_seed(2))
+    wgt = torch.randn(3, 768, generator=torch.Generator().manual_seed(3))
+    grads = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("MMG_BWDW", knob)
+        torch.manual_seed(0)
+        tower = ConvNextTinyEncoder(micro_batch=2)
+        _randomize(tower, 1)
+        tower = tower.to(dev)
+        assert tower.bwdw == (knob == "1")
+        feat = tower(img.to(dev))
+        (feat * wgt.to(dev)).sum().backward()
+        used = any(k.endswith(".bwdw") for k in tower._wc)
+        grads[knob] = ({n: p.grad.detach().float().cpu().clone() for n, p in tower.model.named_parameters()}, used)
+    assert grads["1"][1] and not grads["0"][1]                     # the knob really selects the path
+    worst = max((_rel(grads["1"][0][n], g0) + (n,) for n, g0 in grads["0"][0].items()), key=lambda t: t[0])
+    assert worst[0] < 2e-2 and min(_rel(grads["1"][0][n], g0)[1] for n, g0 in grads["0"][0].items()) > 0.9995, worst
+
+
 @pytest.mark.parametrize("variant,min_c", [("base", 1024), ("tiny", 768), ("base", 128), ("tiny", 384)])
 def test_convnext_fp8_forward_matches_the_fp8_oracle(dev, variant, min_c):
     """BASELINE config C5: e4m3 forward GEMMs (in every block with C % 128 == 0 and C >= min_c) against the oracle that rounds
