@@ -19,6 +19,7 @@
 // The weight-gradient kernel reads both operands with ds_read_b64_tr_b16 (hardware transpose) because the
 // reduction index (the row m) is the slow index of both inputs.
 #include "common.h"
+#include <type_traits>
 #include "gemm_tn.h"
 #include <stdlib.h>
 
@@ -95,11 +96,14 @@ __device__ __forceinline__ void store16(void* dst, const uint4 v, int nt) {
 }
 
 // One output row segment of 8 columns: staged fp32 accumulators -> bias / activation / layer scale / residual -> store.
-// This epilogue is touchy (round 2, same-run A/B of five builds, tools/nt_ab.py): on the 1M x 1536 x 384 GELU' shape the polynomial
-// GELU of common.h was 7 % slower than the rcp / exp form (the epilogue is not VALU-bound; its 9-deep fma chain hides less memory
-// latency), a runtime fp32-residual branch cost 4-6 %, a further co-compiled tile instantiation 3 %: it stays as round 1 left it.
+// EPI is a template parameter (round 3): with the runtime `g.epi` tested inside the element loops, hipcc kept one scalar branch per element
+// PAIR - 64 basic blocks per thread and tile, each a single dependent v_exp -> v_rcp -> fma chain with nothing to interleave (tools/nt_probe.py:
+// 26 000 of the 67 700 cycles of a 256 x 256 x 384 GELU' tile were this arithmetic).  The kernel now switches once per tile (nt_epilogue_slabs)
+// and the eight columns of a row are straight-line code.
+// RES: 1 = a residual row is added, 0 = none, -1 = g.residual decides at run time.
+template <int EPI, int RES = -1>
 __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* crow, int gr, int gc, const float* bias,
-                                                const float* cs, const uint4 res, const uint4 aux, bool want_aux, float alpha) {
+                                                const float* cs, const uint4 res, const uint4 aux, float alpha) {
     float v[8];
     const f32x4 lo = *reinterpret_cast<const f32x4*>(crow);
     const f32x4 hi = *reinterpret_cast<const f32x4*>(crow + 4);
@@ -107,25 +111,33 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
     for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], alpha, bias[e]);
-    if (g.epi == EPI_GELU || g.epi == EPI_RELU) {
+    if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
         if (g.aux_out) {
             uint4 o;
             o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
             store16(g.aux_out + (size_t)gr * g.ldao + gc, o, g.nt_store);
         }
+#ifndef NT_GELU_EXACT        // bf16 / fp8 outputs: the exp-free polynomial of common.h (2^-11 relative, the output rounds at 2^-9); fp32 outputs stay exact
+        if (EPI == EPI_GELU && !g.out_f32) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (g.epi == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
-    } else if (want_aux) {
+            for (int e = 0; e < 8; ++e) v[e] = gelu_bf16(v[e]);
+        } else
+#endif
+        {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (EPI == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
+        }
+    } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
         const unsigned hw[4] = {aux.x, aux.y, aux.z, aux.w};
         unsigned act[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
-            if (g.epi == EPI_DGELU) {
+            if constexpr (EPI == EPI_DGELU) {
                 // the activation itself (needed by the weight-gradient GEMM of the same layer) shares cdf/pdf with
                 // its derivative: emitting it here replaces a separate read-modify-write pass over the [M,N] tensor
                 float a0, d0, a1, d1;
-#ifdef NT_DGELU_POLY        // A/B build (tools/nt_dgelu_tiles.py): two independent exp-free polynomials instead of the shared rcp / exp form
+#ifndef NT_GELU_EXACT       // two exp-free polynomials (common.h; the same pair the fused CNBlock kernels use); -DNT_GELU_EXACT: shared rcp / exp form
                 a0 = gelu_bf16(h0); d0 = gelu_bf16_grad_poly(h0);
                 a1 = gelu_bf16(h1); d1 = gelu_bf16_grad_poly(h1);
 #else
@@ -145,7 +157,7 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= cs[e];
-    if (g.residual) {
+    if (RES == 1 || (RES < 0 && g.residual)) {
         const unsigned rw[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
@@ -161,6 +173,17 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
         uint4 o;
         o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
         store16(reinterpret_cast<bf16_t*>(g.C) + (size_t)gr * g.ldc + gc, o, g.nt_store);
+    }
+}
+// the same with the mode read at run time (kernels whose epilogue is not on a hot path)
+__device__ __forceinline__ void nt_epilogue_row_rt(const GemmNT& g, const float* crow, int gr, int gc, const float* bias,
+                                                   const float* cs, const uint4 res, const uint4 aux, float alpha) {
+    switch (g.epi) {
+        case EPI_GELU: nt_epilogue_row<EPI_GELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
+        case EPI_DGELU: nt_epilogue_row<EPI_DGELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
+        case EPI_RELU: nt_epilogue_row<EPI_RELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
+        case EPI_DRELU: nt_epilogue_row<EPI_DRELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
+        default: nt_epilogue_row<EPI_NONE>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
     }
 }
 
@@ -183,6 +206,33 @@ __device__ __forceinline__ void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifdef NT_PROBE
+// Debug builds only (tools/nt_probe.py): shader-clock totals per phase of gemm_nt_kernel, summed over waves
+//   0 whole kernel  1 set-up (offsets, per-column vectors, first stages issued)  2 main loop  3 epilogue: barriers + accumulators -> LDS
+//   5 epilogue: row arithmetic + stores issued (with the waits for the slab's global reads)  6 waves
+// (one plain store per workgroup slot: 200 000 waves x 8 same-address atomics took 16 ms by themselves)
+#define NT_PROBE_SLOTS 32768
+__device__ unsigned long long g_nt_probe[NT_PROBE_SLOTS][8];
+MMG_API int mmg_debug_nt_probe(unsigned long long* out8, int reset) {
+    static unsigned long long host[NT_PROBE_SLOTS][8];
+    if (out8) {
+        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_nt_probe), sizeof(host)) != hipSuccess) return 1;
+        for (int i = 0; i < 8; ++i) out8[i] = 0;
+        for (int s = 0; s < NT_PROBE_SLOTS; ++s) for (int i = 0; i < 8; ++i) out8[i] += host[s][i];
+    }
+    if (reset) {
+        for (int s = 0; s < NT_PROBE_SLOTS; ++s) for (int i = 0; i < 8; ++i) host[s][i] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_nt_probe), host, sizeof(host)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#define NTP_T(var) const long long var = __builtin_readcyclecounter()
+#define NTP_ADD(idx, a, b) ntp[idx] += (b) - (a)
+#else
+#define NTP_T(var)
+#define NTP_ADD(idx, a, b)
+#endif
+
 template <int BM, int BN, int BK, int WAVES_M, int NST, int F8 = 0>
 __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 128 ? 1 : 2)) void gemm_nt_kernel(const GemmNT g) {
     static_assert(!F8 || BK == 64, "fp8 operands: one 128-byte K tile = one 16x16x128 MFMA step");
@@ -203,6 +253,10 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+#ifdef NT_PROBE
+    long long ntp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    NTP_T(nt_t0);
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -271,6 +325,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
     for (int s = 0; s < NST - 1; ++s)
         if (s < nk) stage(s, s);
 
+    NTP_T(nt_t1);
     for (int kt0 = 0; kt0 < nk; kt0 += NST) {
 #pragma unroll
         for (int s = 0; s < NST; ++s) {
@@ -328,6 +383,8 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
         }
     }
 
+    NTP_T(nt_t2);
+    NTP_ADD(1, nt_t0, nt_t1); NTP_ADD(2, nt_t1, nt_t2);
     // issue EVERY global read of the epilogue (residual / saved pre-activation rows of all passes) before the
     // accumulators go through LDS, so their latency overlaps the staging instead of being paid pass by pass.
     constexpr bool PREFETCH = PASSES <= 8;                // (wider tiles: 16 passes of prefetch would spill)
@@ -344,55 +401,115 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
         if (ok && g.residual) res_v[p] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
         if (ok && want_aux) aux_v[p] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
     }
-    // accumulators -> LDS -> coalesced 16-byte row segments, one 64-row slab (= one wave row) at a time
+    // accumulators -> LDS -> coalesced 16-byte row segments, one 64-row slab (= one wave row) at a time.
+    //  * The epilogue mode is uniform: ONE switch per tile, each arm the whole slab sequence with the mode a constant (tag = mode + 16 * residual;
+    //    tag < 0: the arm for combinations no caller uses - everything read at run time, as round 2 had it for every call).
+    //  * Wide tiles read a slab's residual / saved pre-activation rows one slab AHEAD (NT_EPI_READS_LATE: at the top of their own slab): the reads of
+    //    slab q + 1 are in flight during the arithmetic and the stores of slab q, and vmcnt retires in order, so the wait in front of their first
+    //    use leaves those stores in flight too.  Two register sets, addressed by constants (q & 1) - a copy between sets makes hipcc wait.
+    //  * The slab index is a template constant (a `#pragma unroll` loop of this size is not reliably unrolled).
     float* Cs = reinterpret_cast<float*>(smem);
+    auto epilogue = [&](auto epi_tag) {
+        constexpr int TAG = decltype(epi_tag)::value;
+        constexpr int EPI = TAG < 0 ? -1 : (TAG & 15), RES = TAG < 0 ? -1 : (TAG >> 4);
+        constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DRELU);
+#ifdef NT_EPI_READS_LATE
+        constexpr bool AHEAD = false;
+#else
+        constexpr bool AHEAD = !PREFETCH && TAG >= 0 && (AUX || RES == 1);
+#endif
+        uint4 rs_v[AHEAD ? 2 : 1][PREFETCH ? 1 : QP], as_v[AHEAD ? 2 : 1][PREFETCH ? 1 : QP];
+        auto slab_reads = [&](auto q_tag) {
+            constexpr int q = decltype(q_tag)::value, S = AHEAD ? (q & 1) : 0;
 #pragma unroll
-    for (int q = 0; q < WAVES_M; ++q) {
-        // wide tiles: the slab's own epilogue reads are issued here, ahead of its two barriers
-        uint4 rs_v[PREFETCH ? 1 : QP], as_v[PREFETCH ? 1 : QP];
-        if (!PREFETCH) {
-#pragma unroll
-            for (int hp = 0; hp < QP; ++hp) {
+            for (int hp = 0; hp < (PREFETCH ? 0 : QP); ++hp) {
                 const int rl = tr + hp * RPP;
                 const int gr = m0 + q * 64 + rl;
-                const bool ok = col_ok && (rl < 64) && (gr < g.M);
-                rs_v[hp] = make_uint4(0, 0, 0, 0);
-                as_v[hp] = make_uint4(0, 0, 0, 0);
-                if (ok && g.residual) rs_v[hp] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
-                if (ok && want_aux) as_v[hp] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
+                if constexpr (TAG >= 0) {
+                    // UNCONDITIONAL reads from clamped addresses (rows past the edge re-read row M - 1 and are never stored): with the reads under
+                    // `if (ok)`, hipcc's wait-count pass meets joins where a destination register may still be a pending load of a skipped row and
+                    // puts s_waitcnt vmcnt(0) between the slab's reads - one exposed HBM latency per row instead of one per slab.
+                    const size_t grc = (size_t)min(gr, g.M - 1);
+                    const int gcc = col_ok ? gc : 0;
+                    if constexpr (RES == 1) rs_v[S][hp] = *reinterpret_cast<const uint4*>(g.residual + grc * g.ldr + gcc);
+                    if constexpr (AUX) as_v[S][hp] = *reinterpret_cast<const uint4*>(g.aux_in + grc * g.ldai + gcc);
+                } else {
+                    const bool ok = col_ok && (rl < 64) && (gr < g.M);
+                    rs_v[S][hp] = make_uint4(0, 0, 0, 0);
+                    as_v[S][hp] = make_uint4(0, 0, 0, 0);
+                    if (ok && g.residual) rs_v[S][hp] = *reinterpret_cast<const uint4*>(g.residual + (size_t)gr * g.ldr + gc);
+                    if (ok && want_aux) as_v[S][hp] = *reinterpret_cast<const uint4*>(g.aux_in + (size_t)gr * g.ldai + gc);
+                }
             }
-        }
-        // LDS ordering is all the two slab barriers need: a __syncthreads() also waits for every outstanding global access (vmcnt(0) -
-        // on CDNA4 that counter includes STORES), i.e. for the previous slab's 16-byte output stores and for this slab's own epilogue
-        // reads issued just above - one exposed store / load latency per slab (round 3, MMG_NT_EPI_SYNC A/B build)
+        };
+        auto slab = [&](auto q_tag) {
+            constexpr int q = decltype(q_tag)::value, S = AHEAD ? (q & 1) : 0;
+            NTP_T(nt_s0);
+            if constexpr (!AHEAD) slab_reads(q_tag);
+            // LDS ordering is all the two slab barriers need: a __syncthreads() also waits for every outstanding global access (vmcnt(0) -
+            // on CDNA4 that counter includes STORES), i.e. for the previous slab's 16-byte output stores and for the epilogue reads in flight
 #ifdef NT_EPI_SYNCTHREADS
-        __syncthreads();   // fragment reads (q = 0) / the previous slab's reads are done
+            __syncthreads();   // fragment reads (q = 0) / the previous slab's reads are done
 #else
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-        if (wm == q) {
+            if (wm == q) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    *reinterpret_cast<f32x4*>(Cs + (i * 16 + li) * LDCS + wn * (BN / 2) + j * 16 + 4 * lg) = acc[i][j];
-        }
-#ifdef NT_EPI_SYNCTHREADS
-        __syncthreads();
-#else
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-        if (col_ok) {
-#pragma unroll
-            for (int hp = 0; hp < QP; ++hp) {
-                const int rl = tr + hp * RPP;
-                const int gr = m0 + q * 64 + rl;
-                if (rl < 64 && gr < g.M)
-                    nt_epilogue_row(g, Cs + rl * LDCS + tc, gr, gc, bias, cs, PREFETCH ? res_v[PREFETCH ? q * QP + hp : 0] : rs_v[PREFETCH ? 0 : hp],
-                                    PREFETCH ? aux_v[PREFETCH ? q * QP + hp : 0] : as_v[PREFETCH ? 0 : hp], want_aux, alpha);
+                    for (int j = 0; j < NI; ++j)
+                        *reinterpret_cast<f32x4*>(Cs + (i * 16 + li) * LDCS + wn * (BN / 2) + j * 16 + 4 * lg) = acc[i][j];
             }
+#ifdef NT_EPI_SYNCTHREADS
+            __syncthreads();
+#else
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+            if constexpr (AHEAD && q + 1 < WAVES_M) slab_reads(std::integral_constant<int, q + 1>{});
+            NTP_T(nt_s1);
+            NTP_ADD(3, nt_s0, nt_s1);
+            if (col_ok) {
+#pragma unroll
+                for (int hp = 0; hp < QP; ++hp) {
+                    const int rl = tr + hp * RPP;
+                    const int gr = m0 + q * 64 + rl;
+                    if (rl < 64 && gr < g.M) {
+                        const uint4 rv = PREFETCH ? res_v[PREFETCH ? q * QP + hp : 0] : rs_v[S][PREFETCH ? 0 : hp];
+                        const uint4 av = PREFETCH ? aux_v[PREFETCH ? q * QP + hp : 0] : as_v[S][PREFETCH ? 0 : hp];
+                        if constexpr (TAG >= 0) nt_epilogue_row<EPI, RES>(g, Cs + rl * LDCS + tc, gr, gc, bias, cs, rv, av, alpha);
+                        else nt_epilogue_row_rt(g, Cs + rl * LDCS + tc, gr, gc, bias, cs, rv, av, alpha);
+                    }
+                }
+            }
+            NTP_T(nt_s3);
+            NTP_ADD(5, nt_s1, nt_s3);
+        };
+        if constexpr (AHEAD) slab_reads(std::integral_constant<int, 0>{});
+        slab(std::integral_constant<int, 0>{});
+        slab(std::integral_constant<int, 1>{});
+        if constexpr (WAVES_M > 2) {
+            slab(std::integral_constant<int, 2>{});
+            slab(std::integral_constant<int, 3>{});
         }
+    };
+    switch (g.epi + (g.residual ? 16 : 0)) {
+        case EPI_NONE: epilogue(std::integral_constant<int, EPI_NONE>{}); break;
+        case EPI_NONE + 16: epilogue(std::integral_constant<int, EPI_NONE + 16>{}); break;
+        case EPI_GELU: epilogue(std::integral_constant<int, EPI_GELU>{}); break;
+        case EPI_DGELU: epilogue(std::integral_constant<int, EPI_DGELU>{}); break;
+        case EPI_RELU: epilogue(std::integral_constant<int, EPI_RELU>{}); break;
+        case EPI_RELU + 16: epilogue(std::integral_constant<int, EPI_RELU + 16>{}); break;
+        case EPI_DRELU: epilogue(std::integral_constant<int, EPI_DRELU>{}); break;
+        default: epilogue(std::integral_constant<int, -1>{}); break;
     }
+#ifdef NT_PROBE
+    {
+        NTP_T(nt_t3);
+        ntp[0] = nt_t3 - nt_t0; ntp[6] = 1;
+        if (tid == 0 && blockIdx.x < NT_PROBE_SLOTS)                 // wave 0 of the first 32768 workgroups
+            for (int i = 0; i < 8; ++i) g_nt_probe[blockIdx.x][i] = (unsigned long long)ntp[i];
+    }
+#endif
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int NST, int F8 = 0>

@@ -29,8 +29,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             print(f"  NT M={M} N={N} K={K} {mode:9s} {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
 else:
     sets = [{}, {"MMG_GEMM_256": "0"}, {"MMG_GEMM_256": "0", "MMG_GEMM_KBIG": "128"}, {}]
-    # A/B builds of gemm_bf16.hip (linked into tools/libmmg_ab_<name>.so): --lib ntpoly = -DNT_DGELU_POLY (two exp-free polynomials in the
-    # GELU' epilogue), --lib ntsync = -DNT_EPI_SYNCTHREADS (the epilogue's slab barriers as __syncthreads(), i.e. with vmcnt(0): round 2)
+    # A/B builds of gemm_bf16.hip (linked into tools/libmmg_ab_<name>.so): --lib ntexact = -DNT_GELU_EXACT (rcp / exp GELU forms instead of the
+    # polynomials), --lib ntlate = -DNT_EPI_READS_LATE (a slab's epilogue reads at the top of the slab), --lib ntsync = -DNT_EPI_SYNCTHREADS
+    # (slab barriers as __syncthreads(), i.e. with vmcnt(0): round 2), --lib ntold = the file as of the previous commit (tools/nt_epi_ab.sh)
     if "--lib" in sys.argv:
         alt = os.path.join(ROOT, "tools", "libmmg_ab_%s.so" % sys.argv[sys.argv.index("--lib") + 1])
         sets = [{}, {"MMGCLIP_HIP_LIB": alt}, {}, {"MMGCLIP_HIP_LIB": alt}]
