@@ -130,29 +130,37 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
     } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
         const unsigned hw[4] = {aux.x, aux.y, aux.z, aux.w};
         unsigned act[4];
+        // the activation itself (needed by the weight-gradient GEMM of the same layer) is emitted beside its derivative: that replaces a separate
+        // read-modify-write pass over the [M,N] tensor.  bf16 / fp8 data gradients: two exp-free polynomials (common.h - the pair the fused CNBlock
+        // kernels use; 2^-11 against an output that rounds at 2^-9); fp32 data gradients: the shared rcp / exp form (1.5e-7).  -DNT_GELU_EXACT: always.
+        auto pairs = [&](auto poly_tag) {
+            constexpr bool POLY = decltype(poly_tag)::value;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
-            if constexpr (EPI == EPI_DGELU) {
-                // the activation itself (needed by the weight-gradient GEMM of the same layer) shares cdf/pdf with
-                // its derivative: emitting it here replaces a separate read-modify-write pass over the [M,N] tensor
-                float a0, d0, a1, d1;
-#ifndef NT_GELU_EXACT       // two exp-free polynomials (common.h; the same pair the fused CNBlock kernels use); -DNT_GELU_EXACT: shared rcp / exp form
-                a0 = gelu_bf16(h0); d0 = gelu_bf16_grad_poly(h0);
-                a1 = gelu_bf16(h1); d1 = gelu_bf16_grad_poly(h1);
-#else
-                gelu_both(h0, a0, d0);
-                gelu_both(h1, a1, d1);
-#endif
-                v[2 * e] *= d0;
-                v[2 * e + 1] *= d1;
-                act[e] = pack2bf(a0, a1);
-            } else {
-                act[e] = pack2bf(fmaxf(h0, 0.f), fmaxf(h1, 0.f));
-                v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;
-                v[2 * e + 1] = h1 > 0.f ? v[2 * e + 1] : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
+                if constexpr (EPI == EPI_DGELU) {
+                    float a0, d0, a1, d1;
+                    if constexpr (POLY) {
+                        a0 = gelu_bf16(h0); d0 = gelu_bf16_grad_poly(h0);
+                        a1 = gelu_bf16(h1); d1 = gelu_bf16_grad_poly(h1);
+                    } else {
+                        gelu_both(h0, a0, d0);
+                        gelu_both(h1, a1, d1);
+                    }
+                    v[2 * e] *= d0;
+                    v[2 * e + 1] *= d1;
+                    act[e] = pack2bf(a0, a1);
+                } else {
+                    act[e] = pack2bf(fmaxf(h0, 0.f), fmaxf(h1, 0.f));
+                    v[2 * e] = h0 > 0.f ? v[2 * e] : 0.f;
+                    v[2 * e + 1] = h1 > 0.f ? v[2 * e + 1] : 0.f;
+                }
             }
-        }
+        };
+#ifndef NT_GELU_EXACT
+        if (EPI == EPI_DGELU && !g.out_f32) pairs(std::true_type{}); else
+#endif
+        pairs(std::false_type{});
         if (g.aux_out) store16(g.aux_out + (size_t)gr * g.ldao + gc, make_uint4(act[0], act[1], act[2], act[3]), g.nt_store);
     }
 #pragma unroll

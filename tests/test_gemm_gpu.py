@@ -58,6 +58,12 @@ def test_nt_epilogues(dev, M, N, K):
     x = hh.float().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
     np.testing.assert_allclose(y.cpu().numpy(), ((a.float() @ b.float().t()) * x.grad).cpu().numpy(), rtol=1e-3, atol=1e-3)
+    # the same with a bf16 data gradient, as the towers call it: GELU / GELU' by the exp-free polynomials (2^-11; the output rounds at 2^-9)
+    act2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    y2 = linalg.gemm_nt(a, b, epi=linalg.EPI_DGELU, aux_in=hh, aux_out=act2)
+    assert y2.dtype == torch.bfloat16
+    np.testing.assert_allclose(y2.float().cpu().numpy(), ((a.float() @ b.float().t()) * x.grad).cpu().numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(act2.float().cpu().numpy(), torch.nn.functional.gelu(hh.float()).cpu().numpy(), rtol=1e-2, atol=1e-2)
     # ReLU pair
     y = linalg.gemm_nt(a, b, bias=bias, epi=linalg.EPI_RELU, out_dtype=torch.float32)
     np.testing.assert_allclose(y.cpu().numpy(), torch.relu(pre).cpu().numpy(), rtol=1e-4, atol=1e-3)
