@@ -230,6 +230,137 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const LNArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The image tower's LayerNorms (round 3): bf16 rows of C = 24 G elements, G lanes x 3 chunks per row, every lane busy, no fp32 / fp8 / residual
+// variants and therefore no run-time mode branches around the loads.  What bounds these kernels is bytes in flight (tools/micro/hbm_mix.hip:
+// a copy needs ~40 KB of reads in flight per CU for 5.3 TB/s): a wave here has 64 / G rows x 3 chunks x 16 B per operand outstanding - 3 KB
+// against the 0.75 - 1 KB of the generic kernels at the widths 96 / 192 / 384 (one chunk per lane, a quarter of the lanes idle) - and the
+// backward keeps its operands PACKED between its two passes (8 registers per chunk instead of 16 floats), which is what lets three chunks
+// per lane fit four waves per SIMD (the generic backward with CH = 3 needed 158 VGPRs and got slower).
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void layernorm_fwd_plain_kernel(const LNArgs a) {
+    constexpr int RPW = 64 / G, CH = 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gr = lane / G;
+    float gam[CH][8], bet[CH][8];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = gl + k * G;
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c * 8), g1 = *reinterpret_cast<const float4*>(a.gamma + c * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(a.beta + c * 8), b1 = *reinterpret_cast<const float4*>(a.beta + c * 8 + 4);
+        gam[k][0] = g0.x; gam[k][1] = g0.y; gam[k][2] = g0.z; gam[k][3] = g0.w; gam[k][4] = g1.x; gam[k][5] = g1.y; gam[k][6] = g1.z; gam[k][7] = g1.w;
+        bet[k][0] = b0.x; bet[k][1] = b0.y; bet[k][2] = b0.z; bet[k][3] = b0.w; bet[k][4] = b1.x; bet[k][5] = b1.y; bet[k][6] = b1.z; bet[k][7] = b1.w;
+    }
+    const float inv_c = 1.0f / (float)a.C;
+    const int rows_per_block = 4 * RPW;
+    for (int m = blockIdx.x * rows_per_block + wave * RPW + gr; m < a.M; m += gridDim.x * rows_per_block) {
+        uint4 raw[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) raw[k] = *reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx + (gl + k * G) * 8);
+        float v[CH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            unpack8(raw[k], v[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[k][e];
+        }
+        const float mu = group_sum<G>(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[k][e] -= mu; q += v[k][e] * v[k][e]; }
+        const float rs = rsqrtf(group_sum<G>(q) * inv_c + a.eps);
+        const size_t obase = ln_out_offset(a, m, a.ldy);
+        if (obase != (size_t)-1) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = v[k][e] * rs * gam[k][e] + bet[k][e];
+                store16_stream(a.y + obase + (gl + k * G) * 8, pack8(o), a.nt);
+            }
+        }
+        if (gl == 0) {
+            if (a.mean) a.mean[m] = mu;
+            if (a.rstd) a.rstd[m] = rs;
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_plain_kernel(const LNArgs a) {
+    constexpr int RPW = 64 / G, CH = 3;
+    extern __shared__ float red[];    // [2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = lane % G, gr = lane / G;
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float gam[CH][8], dg[CH][8], db[CH][8];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = gl + k * G;
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + c * 8), g1 = *reinterpret_cast<const float4*>(a.gamma + c * 8 + 4);
+        gam[k][0] = g0.x; gam[k][1] = g0.y; gam[k][2] = g0.z; gam[k][3] = g0.w; gam[k][4] = g1.x; gam[k][5] = g1.y; gam[k][6] = g1.z; gam[k][7] = g1.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[k][e] = 0.f; db[k][e] = 0.f; }
+    }
+    const float inv_c = 1.0f / (float)a.C;
+    const int rows_per_block = 4 * RPW;
+    for (int m = blockIdx.x * rows_per_block + wave * RPW + gr; m < a.M; m += gridDim.x * rows_per_block) {
+        const size_t gbase = ln_out_offset(a, m, a.lddy);
+        uint4 xr[CH], dr[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            xr[k] = *reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx + (gl + k * G) * 8);
+            dr[k] = *reinterpret_cast<const uint4*>(a.dy + gbase + (gl + k * G) * 8);
+        }
+        const float mu = a.mean[m], rs = a.rstd[m];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            float xv[8], dyv[8];
+            unpack8(xr[k], xv);
+            unpack8(dr[k], dyv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (xv[e] - mu) * rs, g = dyv[e] * gam[k][e];
+                s1 += g;
+                s2 += g * xh;
+                dg[k][e] += dyv[e] * xh;
+                db[k][e] += dyv[e];
+            }
+        }
+        s1 = group_sum<G>(s1) * inv_c;
+        s2 = group_sum<G>(s2) * inv_c;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            float xv[8], dyv[8], o[8];
+            unpack8(xr[k], xv);
+            unpack8(dr[k], dyv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rs * (dyv[e] * gam[k][e] - s1 - (xv[e] - mu) * rs * s2);
+            store16_stream(a.dx + (size_t)m * a.lddx + (gl + k * G) * 8, pack8(o), a.nt);
+        }
+    }
+    if (a.dgamma) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(&red[(gl + k * G) * 8 + e], dg[k][e]);
+                atomicAdd(&red[a.C + (gl + k * G) * 8 + e], db[k][e]);
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.C; i += 256) {
+            atomicAdd(a.dgamma + i, red[i]);
+            atomicAdd(a.dbeta + i, red[a.C + i]);
+        }
+    }
+}
+
 template <bool BWD>
 static int launch_ln(const LNArgs& a, hipStream_t stream) {
     const int nch = a.C / 8;
@@ -244,11 +375,32 @@ static int launch_ln(const LNArgs& a, hipStream_t stream) {
     static const int ch3_on = getenv("MMG_LN_CH3") ? atoi(getenv("MMG_LN_CH3")) : 1;
     const bool ch3 = !BWD && ch3_on && nch % 3 == 0 && (nch / 3 == 8 || nch / 3 == 16 || nch / 3 == 32 || nch / 3 == 64);
     if (ch3) { G = nch / 3; ch = 3; }
+    // the image tower's widths on the plain kernels above (MMG_LN_PLAIN=0: off, A/B)
+    static const int plain_on = getenv("MMG_LN_PLAIN") ? atoi(getenv("MMG_LN_PLAIN")) : 1;
+    const int g3 = nch % 3 == 0 ? nch / 3 : 0;
+    const bool plain = plain_on && (g3 == 4 || g3 == 8 || g3 == 16 || g3 == 32 || g3 == 64) && !a.x_f32 && !a.res && !a.y_fp8 && !a.yf && !a.add &&
+                       (!BWD || (a.mean && a.rstd));
+    if (plain) G = g3;
     const int rows_per_block = 4 * (64 / G);
     int blocks = cdiv(a.M, rows_per_block);
     const int cap = BWD ? 1024 : 4096;
     if (blocks > cap) blocks = cap;
     const size_t shm = BWD ? 2 * a.C * sizeof(float) : 0;
+    if (plain) {
+#define LN_PLAIN(GG)                                                                                                      \
+    do {                                                                                                                  \
+        MMG_NOTE_KERNEL(BWD ? "layernorm_bwd_plain_kernel<%d>" : "layernorm_fwd_plain_kernel<%d>", GG);                   \
+        if (BWD) hipLaunchKernelGGL((layernorm_bwd_plain_kernel<GG>), dim3(blocks), dim3(256), shm, stream, a);           \
+        else hipLaunchKernelGGL((layernorm_fwd_plain_kernel<GG>), dim3(blocks), dim3(256), 0, stream, a);                 \
+    } while (0)
+        if (G == 4) LN_PLAIN(4);
+        else if (G == 8) LN_PLAIN(8);
+        else if (G == 16) LN_PLAIN(16);
+        else if (G == 32) LN_PLAIN(32);
+        else LN_PLAIN(64);
+#undef LN_PLAIN
+        return 0;
+    }
 #define LN_LAUNCH(GG, CC)                                                                                       \
     do {                                                                                                        \
         MMG_NOTE_KERNEL(BWD ? "layernorm_bwd_kernel<%d, %d>" : "layernorm_fwd_kernel<%d, %d>", GG, CC);         \

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""LayerNorm forward / backward on the C2 shapes under the round-2 lane-group selection and the 3-chunk one (MMG_LN_CH3=0 / 1; the knob is
+"""LayerNorm forward / backward on the C2 shapes under the generic kernels and the plain 3-chunk ones (MMG_LN_PLAIN=0 / 1; the knob is
 read once per process: one child per setting, twice each)."""
 import os
 import subprocess
@@ -30,5 +30,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print(f"  M={M:9d} C={C:4d}  " + "   ".join(res), flush=True)
 else:
     for knob in ("0", "1", "0", "1"):
-        print("== MMG_LN_CH3=" + knob, flush=True)
-        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env={**os.environ, "MMG_LN_CH3": knob})
+        print("== MMG_LN_PLAIN=" + knob, flush=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env={**os.environ, "MMG_LN_PLAIN": knob})
