@@ -93,7 +93,9 @@ int mmg_clip_loss_reduce(const float* lse_a, const float* pos_a, const float* ls
  * epilogue (in this order): + bias[N];  activation by `epi`:
  *     0 none | 1 GELU(erf) (aux_out, when given, receives the pre-activation) | 2 multiply by GELU'(aux_in)
  *     (aux_out, when given, receives GELU(aux_in): the activation rebuilt for the weight-gradient GEMM)
- *     3 ReLU (aux_out as 1)  | 4 ReLU' (gate by aux_in > 0; aux_out as 2);
+ *     3 ReLU (aux_out as 1)  | 4 ReLU' (gate by aux_in > 0; aux_out as 2)  | 5 multiply by GELU'(aux_in) only (ABI 4: for callers that
+ *     kept GELU(h) from the forward; aux_out unused);  bf16 / e4m3 outputs of 1, 2 and 5 evaluate GELU / GELU' by the polynomials of
+ *     csrc/common.h (2^-11 relative), fp32 outputs by the erf form (1.5e-7);
  * then * colscale[N] (ConvNeXt layer scale), + residual[M,N] (bf16); C is bf16 (out_f32 = 0) or fp32.
  * K % 32 == 0, N % 8 == 0, leading dimensions multiples of 8.
  * Replaces nn.Linear forward / data-gradient in HF BertLayer (reference call site mmgclip/networks/encoder.py:156),
@@ -203,10 +205,12 @@ int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamm
  * Replaces CNBlock.block[2..5] + layer_scale + residual of torchvision ConvNeXt (mmgclip/networks/encoder.py:53) in one
  * launch: the 4C-wide hidden row stays in registers.  hpre (bf16 [M,4C], pre-GELU) and mean/rstd (fp32 [M]) are optional (all three or none)
  * outputs for a backward that does not recompute them; xln (bf16 [M,C], the LayerNorm output = operand of that backward's
- * weight-gradient GEMM; optional, only next to hpre) saves it a LayerNorm pass.  (ABI 2: xln added.) */
+ * weight-gradient GEMM; optional, only next to hpre) saves it a LayerNorm pass; gact (bf16 [M,4C], GELU(hidden) as the second GEMM
+ * consumed it; optional, only next to hpre) is the operand of that backward's dW2 GEMM, which lets its data-gradient GEMM run
+ * epilogue 5 (GELU' only) instead of 2.  (ABI 2: xln added; ABI 4: gact added.) */
 int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
                         const float* b1, const float* b2, const float* gamma, const void* residual, void* y, void* hpre,
-                        void* xln, float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
+                        void* xln, void* gact, float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
 
 /* Data path of the CNBlock MLP backward in one launch.  mmg_cnblock_mlp_bwd_supported(C): 1 (C in {96,128,192}) = the
  * hidden row h = LN(xd) W1^T + b1 is recomputed from the saved depthwise output, packed_bwd = pack(..., backward=1), hpre must

@@ -36,6 +36,7 @@ struct MlpFwd {
     float* mean; float* rstd;               // optional [M]
     long M; int ntiles;
     int nt;                                 // 4C-wide output larger than the Infinity Cache: store it past L2 (nontemporal)
+    bf16_t* gact;                           // optional [M,4C] GELU(hidden) as the second GEMM consumed it (operand of that backward's dW2 GEMM)
 };
 
 __device__ __forceinline__ void mlp_glds16(const void* gsrc, void* lds_wave_base) {
@@ -259,6 +260,13 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
                     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
                     gf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{pack2bf(gelu_bf16(h0[0]), gelu_bf16(h0[1])), pack2bf(gelu_bf16(h0[2]), gelu_bf16(h0[3])),
                                                                  pack2bf(gelu_bf16(h1[0]), gelu_bf16(h1[1])), pack2bf(gelu_bf16(h1[2]), gelu_bf16(h1[3]))}));
+                    if (SAVE) {
+                        const long row = row0 + 16 * mi;
+                        if (p.gact && row < p.M) {
+                            const u32x4_t gw = __builtin_bit_cast(u32x4_t, gf[mi]);
+                            store16_stream(p.gact + row * (4 * C) + n0, make_uint4(gw[0], gw[1], gw[2], gw[3]), p.nt);
+                        }
+                    }
                 }
 #if defined(MLP_PROBE) && MLP_PROBE >= 2
                 asm volatile("" : "+v"(gf[0]), "+v"(gf[MT - 1]));
@@ -683,15 +691,16 @@ MMG_API int mmg_cnblock_pack_weights(const float* w1, const float* w2, const flo
 
 MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
                                 const float* b1, const float* b2, const float* gamma, const void* residual, void* y,
-                                void* hpre, void* xln, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
+                                void* hpre, void* xln, void* gact, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
     MMG_CHECK_ARG(xd && ln_w && ln_b && packed && b1 && b2 && gamma && residual && y, "mmg_cnblock_mlp_fwd: null pointer");
     MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_mlp_fwd: C=%d not in {96,128,192,256,384,512}", C);
     MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_fwd: bad M=%lld", M);
     MMG_CHECK_ARG((mean == nullptr) == (hpre == nullptr) && (rstd == nullptr) == (hpre == nullptr),
                   "mmg_cnblock_mlp_fwd: hpre, mean and rstd are saved together or not at all");
     MMG_CHECK_ARG(!xln || hpre, "mmg_cnblock_mlp_fwd: xln is saved next to hpre only");
+    MMG_CHECK_ARG(!gact || hpre, "mmg_cnblock_mlp_fwd: gact is saved next to hpre only");
     MlpFwd p{(const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed, b1, b2, gamma, (const bf16_t*)residual, (bf16_t*)y,
-             (bf16_t*)hpre, (bf16_t*)xln, mean, rstd, (long)M, 0, 0};
+             (bf16_t*)hpre, (bf16_t*)xln, mean, rstd, (long)M, 0, 0, (bf16_t*)gact};
     switch (C) {
         case 96: return launch_mlp_fwd<96>(p, stream);
         case 128: return launch_mlp_fwd<128>(p, stream);

@@ -25,7 +25,9 @@
 
 #define GEMM_THREADS 256
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RELU = 3, EPI_DRELU = 4 };
+// EPI_DGELU_ONLY: the data gradient alone, C = (A B^T) * GELU'(aux_in) - for callers whose forward kept GELU(h) (round 3: the epilogue of
+// EPI_DGELU is VALU-bound and half of its arithmetic and stores rebuild that activation)
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RELU = 3, EPI_DRELU = 4, EPI_DGELU_ONLY = 5 };
 
 struct GemmNT {
     const bf16_t* A; const bf16_t* B;
@@ -34,7 +36,7 @@ struct GemmNT {
     const float* bias;        // [N]  added to the accumulator
     const float* colscale;    // [N]  multiplies after activation (ConvNeXt layer scale)
     const bf16_t* residual; int ldr;   // [M,N] added last
-    const bf16_t* aux_in; int ldai;    // [M,N] pre-activation for EPI_DGELU / EPI_DRELU
+    const bf16_t* aux_in; int ldai;    // [M,N] pre-activation for EPI_DGELU / EPI_DGELU_ONLY / EPI_DRELU
     bf16_t* aux_out; int ldao;         // [M,N] receives the pre-activation for EPI_GELU / EPI_RELU (may be null)
     int epi;
     float alpha;
@@ -127,7 +129,7 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (EPI == EPI_GELU) ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
         }
-    } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+    } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DGELU_ONLY || EPI == EPI_DRELU) {
         const unsigned hw[4] = {aux.x, aux.y, aux.z, aux.w};
         unsigned act[4];
         // the activation itself (needed by the weight-gradient GEMM of the same layer) is emitted beside its derivative: that replaces a separate
@@ -138,7 +140,10 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float h0 = bf2f_lo(hw[e]), h1 = bf2f_hi(hw[e]);
-                if constexpr (EPI == EPI_DGELU) {
+                if constexpr (EPI == EPI_DGELU_ONLY) {
+                    v[2 * e] *= POLY ? gelu_bf16_grad_poly(h0) : gelu_grad_f(h0);
+                    v[2 * e + 1] *= POLY ? gelu_bf16_grad_poly(h1) : gelu_grad_f(h1);
+                } else if constexpr (EPI == EPI_DGELU) {
                     float a0, d0, a1, d1;
                     if constexpr (POLY) {
                         a0 = gelu_bf16(h0); d0 = gelu_bf16_grad_poly(h0);
@@ -158,10 +163,11 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
             }
         };
 #ifndef NT_GELU_EXACT
-        if (EPI == EPI_DGELU && !g.out_f32) pairs(std::true_type{}); else
+        if ((EPI == EPI_DGELU || EPI == EPI_DGELU_ONLY) && !g.out_f32) pairs(std::true_type{}); else
 #endif
         pairs(std::false_type{});
-        if (g.aux_out) store16(g.aux_out + (size_t)gr * g.ldao + gc, make_uint4(act[0], act[1], act[2], act[3]), g.nt_store);
+        if constexpr (EPI != EPI_DGELU_ONLY)
+            if (g.aux_out) store16(g.aux_out + (size_t)gr * g.ldao + gc, make_uint4(act[0], act[1], act[2], act[3]), g.nt_store);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= cs[e];
@@ -191,6 +197,7 @@ __device__ __forceinline__ void nt_epilogue_row_rt(const GemmNT& g, const float*
         case EPI_DGELU: nt_epilogue_row<EPI_DGELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
         case EPI_RELU: nt_epilogue_row<EPI_RELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
         case EPI_DRELU: nt_epilogue_row<EPI_DRELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
+        case EPI_DGELU_ONLY: nt_epilogue_row<EPI_DGELU_ONLY>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
         default: nt_epilogue_row<EPI_NONE>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
     }
 }
@@ -242,7 +249,7 @@ MMG_API int mmg_debug_nt_probe(unsigned long long* out8, int reset) {
 #endif
 
 template <int BM, int BN, int BK, int WAVES_M, int NST, int F8 = 0>
-__global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 128 ? 1 : 2)) void gemm_nt_kernel(const GemmNT g) {
+__global__ __launch_bounds__(WAVES_M * 128, BN > 128 ? 1 : ((NST == 3 && BK == 32) ? 3 : 2)) void gemm_nt_kernel(const GemmNT g) {
     static_assert(!F8 || BK == 64, "fp8 operands: one 128-byte K tile = one 16x16x128 MFMA step");
     constexpr int THREADS = WAVES_M * 128;
     constexpr int MI = 4, NI = BN / 32;                  // 16x16 fragments per wave (wave tile 64 x BN/2)
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
     // accumulators go through LDS, so their latency overlaps the staging instead of being paid pass by pass.
     constexpr bool PREFETCH = PASSES <= 8;                // (wider tiles: 16 passes of prefetch would spill)
     uint4 res_v[PREFETCH ? PASSES : 1], aux_v[PREFETCH ? PASSES : 1];
-    const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DRELU);
+    const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DGELU_ONLY || g.epi == EPI_DRELU);
     const float alpha = g.alpha_dev ? g.alpha * *g.alpha_dev : g.alpha;
 #pragma unroll
     for (int p = 0; p < (PREFETCH ? PASSES : 0); ++p) {
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
     auto epilogue = [&](auto epi_tag) {
         constexpr int TAG = decltype(epi_tag)::value;
         constexpr int EPI = TAG < 0 ? -1 : (TAG & 15), RES = TAG < 0 ? -1 : (TAG >> 4);
-        constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DRELU);
+        constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DGELU_ONLY || EPI == EPI_DRELU);
 #ifdef NT_EPI_READS_LATE
         constexpr bool AHEAD = false;
 #else
@@ -508,6 +515,7 @@ __global__ __launch_bounds__(WAVES_M * 128, (NST == 3 && BK == 32) ? 3 : (BN > 1
         case EPI_RELU: epilogue(std::integral_constant<int, EPI_RELU>{}); break;
         case EPI_RELU + 16: epilogue(std::integral_constant<int, EPI_RELU + 16>{}); break;
         case EPI_DRELU: epilogue(std::integral_constant<int, EPI_DRELU>{}); break;
+        case EPI_DGELU_ONLY: epilogue(std::integral_constant<int, EPI_DGELU_ONLY>{}); break;
         default: epilogue(std::integral_constant<int, -1>{}); break;
     }
 #ifdef NT_PROBE
@@ -544,8 +552,8 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     MMG_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0,
                   "mmg_gemm_nt_bf16: leading dimensions must cover the row and be multiples of 8 (lda=%d ldb=%d ldc=%d)",
                   lda, ldb, ldc);
-    MMG_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_DRELU, "mmg_gemm_nt_bf16: unknown epilogue %d", epi);
-    MMG_CHECK_ARG(!(epi == EPI_DGELU || epi == EPI_DRELU) || (aux_in && ldai >= N && ldai % 8 == 0),
+    MMG_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_DGELU_ONLY, "mmg_gemm_nt_bf16: unknown epilogue %d", epi);
+    MMG_CHECK_ARG(!(epi == EPI_DGELU || epi == EPI_DGELU_ONLY || epi == EPI_DRELU) || (aux_in && ldai >= N && ldai % 8 == 0),
                   "mmg_gemm_nt_bf16: activation-gradient epilogue needs aux_in");
     MMG_CHECK_ARG(!residual || (ldr >= N && ldr % 8 == 0), "mmg_gemm_nt_bf16: bad ldr=%d", ldr);
     MMG_CHECK_ARG(!aux_out || (ldao >= N && ldao % 8 == 0), "mmg_gemm_nt_bf16: bad ldao=%d", ldao);
@@ -579,6 +587,8 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     auto fill = [](long wgs) { return (double)wgs / (double)(cdiv(wgs, 256) * 256L); };
     const double f256 = fill((long)cdiv(M, 256) * cdiv(N, 256)), f128 = fill((long)cdiv(M, 256) * cdiv(N, 128));
     const bool fills = !fill_rule || f256 >= 0.8 * f128;
+    // (round 3, tools/nt_deep_ab.sh: the same tile on 32-column stages, three or four of them - more K tiles in flight at short K - was 2-3 %
+    // SLOWER on the K = 384 / 768 fat-epilogue shapes, 2883 / 2915 against 2827 us: the main loop is not waiting for its operands.  Removed.)
     if (use_256 && k64 && N % 256 == 0 && M >= 4096 && K >= use_256 && fills) launch_nt<256, 256, 64, 4, 2>(g, stream);
     else if (use_3wg && !n96 && K % 32 == 0 && K < k3_max) launch_nt<128, 128, 32, 2, 3>(g, stream);
     else if (use_big && k64 && !n96 && M >= 4096 && K >= kbig_min) launch_nt<256, 128, 64, 4, 3>(g, stream);

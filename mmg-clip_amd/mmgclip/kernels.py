@@ -176,20 +176,24 @@ def cnblock_pack(w1, w2, gamma=None, backward=False):
     return out
 
 
-def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_hpre=False, want_stats=False, want_xln=False):
-    """-> y, hpre, mean, rstd (and, with want_xln, the LayerNorm output as a fifth value)."""
+def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_hpre=False, want_stats=False, want_xln=False, want_gact=False):
+    """-> y, hpre, mean, rstd (and, with want_xln, the LayerNorm output as a fifth value; with want_gact, GELU(hidden) - the activation as
+    the second GEMM consumed it, bf16 [M,4C] - as the last value)."""
     M, C = xd.shape
     y = torch.empty_like(xd)
     hpre = torch.empty(M, 4 * C, device=xd.device, dtype=BF16) if want_hpre else None
     xln = torch.empty(M, C, device=xd.device, dtype=BF16) if (want_xln and want_hpre) else None
+    gact = torch.empty(M, 4 * C, device=xd.device, dtype=BF16) if (want_gact and want_hpre) else None
     assert want_hpre == want_stats, "hpre and the LN statistics are saved together"
     mean = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
     rstd = torch.empty(M, device=xd.device, dtype=torch.float32) if want_stats else None
-    PROFILE.timed("cnblock_mlp_fwd_kernel", 16.0 * M * C * C, (6 + (8 if want_hpre else 0) + (2 if xln is not None else 0)) * M * C + 16 * C * C,
+    PROFILE.timed("cnblock_mlp_fwd_kernel", 16.0 * M * C * C,
+                  (6 + (8 if want_hpre else 0) + (2 if xln is not None else 0) + (8 if gact is not None else 0)) * M * C + 16 * C * C,
                   lambda: call("mmg_cnblock_mlp_fwd", ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed), ptr(b1), ptr(b2),
-                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(xln), ptr(mean), ptr(rstd), M, C, stream()),
-                  f"M={M} C={C}" + (" +hpre" if want_hpre else "") + (" +xln" if xln is not None else ""))
-    return (y, hpre, mean, rstd, xln) if want_xln else (y, hpre, mean, rstd)
+                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(xln), ptr(gact), ptr(mean), ptr(rstd), M, C, stream()),
+                  f"M={M} C={C}" + (" +hpre" if want_hpre else "") + (" +xln" if xln is not None else "") + (" +gact" if gact is not None else ""))
+    out = (y, hpre, mean, rstd) + ((xln,) if want_xln else ())
+    return out + ((gact,) if want_gact else ())
 
 
 def cnblock_bwd_mode(C):

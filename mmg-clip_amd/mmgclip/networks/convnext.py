@@ -97,6 +97,11 @@ class ConvNextTower(nn.Module):
         # 31 GB on top of 267 GiB of activations, off).  MMG_SAVE_LN=0 / 1 force it.
         self.save_ln_mode = os.environ.get("MMG_SAVE_LN", "auto")
         self.save_ln = self.save_ln_mode == "1"
+        # the same blocks also keep GELU(hidden) ([M,4C] bf16) from the forward, so that the backward's data-gradient GEMM applies GELU' only
+        # (its epilogue is VALU-bound and half of it rebuilt that activation) - decided per forward like save_ln, while those copies stay
+        # below 15 % of the device memory (C2: 33.8 GB on; ConvNeXt-B without checkpointing: 131 GB, off).  MMG_SAVE_GELU=0 / 1 force it.
+        self.save_gelu_mode = os.environ.get("MMG_SAVE_GELU", "auto")
+        self.save_gelu = self.save_gelu_mode == "1"
         self.checkpoint = checkpoint        # recompute each micro-batch's forward in the backward (north-star config C5)
         # fp8 (config C5): the two pointwise GEMMs of every block with C % 128 == 0 and C >= fp8_min_channels run their FORWARD
         # on e4m3 operands (LayerNorm / GELU outputs cast unscaled, weights with a per-tensor power-of-two scale); the backward
@@ -174,15 +179,22 @@ class ConvNextTower(nn.Module):
 
     def _decide_save_ln(self, n_alive, H, W, device):
         """n_alive = images whose saved tensors are alive at once (the whole batch; one micro-batch under checkpointing)."""
-        if self.save_ln_mode in ("0", "1"):
-            return self.save_ln_mode == "1"
         extra, hh, ww = 0, H // 4, W // 4
         for si in range(4):
             C = self.dims[si]
             if not (K.cnblock_supported(C) and K.cnblock_bwd_mode(C) == 1) and not (K.cnblock_bwd_mode(C) == 2 and self.fused_bwd_saved_h):
                 extra += self.depths[si] * n_alive * hh * ww * C * 2
             hh, ww = hh // 2, ww // 2
-        return extra <= 0.04 * torch.cuda.get_device_properties(device).total_memory
+        total = torch.cuda.get_device_properties(device).total_memory
+        if self.save_ln_mode in ("0", "1"):
+            ln = self.save_ln_mode == "1"
+        else:
+            ln = extra <= 0.04 * total
+        if self.save_gelu_mode in ("0", "1"):
+            self.save_gelu = self.save_gelu_mode == "1"
+        else:
+            self.save_gelu = 4 * extra <= 0.15 * total            # ([M,4C] against [M,C])
+        return ln
 
     # ---- forward / backward over one micro-batch -----------------------------------------------------------
     def _forward_mb(self, img, save):
@@ -207,15 +219,16 @@ class ConvNextTower(nn.Module):
                     # a GEMM-pair backward (C = 384 by default) also gets the LayerNorm output from the forward's registers: one
                     # [M,C] store instead of a LayerNorm pass over d in the backward
                     keep_ln = keep and self.save_ln and key + ".mlpb2" not in wc
-                    xn, hpre, mean, rstd, ln = K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS,
-                                                                 wc[key + ".mlp"], blk.block[3].bias.data, blk.block[5].bias.data,
-                                                                 blk.layer_scale.data.reshape(C), x, want_hpre=keep, want_stats=keep,
-                                                                 want_xln=True)[:5] if keep_ln else \
-                        K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, wc[key + ".mlp"],
-                                          blk.block[3].bias.data, blk.block[5].bias.data, blk.layer_scale.data.reshape(C), x,
-                                          want_hpre=keep, want_stats=keep) + (None,)
+                    # ... and (save_gelu) GELU(hidden) as the second GEMM consumed it: that backward's data-gradient GEMM then applies GELU' only
+                    keep_g = keep and self.save_gelu and key + ".mlpb2" not in wc
+                    outs = K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, wc[key + ".mlp"],
+                                             blk.block[3].bias.data, blk.block[5].bias.data, blk.layer_scale.data.reshape(C), x,
+                                             want_hpre=keep, want_stats=keep, want_xln=keep_ln, want_gact=keep_g)
+                    xn, hpre, mean, rstd = outs[:4]
+                    ln = outs[4] if keep_ln else None
+                    gact = outs[-1] if keep_g else None
                     if save:
-                        saved[key] = (x, d, mean, rstd, hpre, ln)
+                        saved[key] = (x, d, mean, rstd, hpre, ln, gact)
                     x = xn
                     continue
                 hpre = torch.empty(x.shape[0], 4 * C, device=x.device, dtype=torch.bfloat16) if save else None
@@ -230,8 +243,9 @@ class ConvNextTower(nn.Module):
                     g = L.gemm_nt(ln, wc[key + ".w1"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre)
                     xn = L.gemm_nt(g, wc[key + ".w2"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
                                    residual=x)
-                if save:                         # (an e4m3 LayerNorm output is not what the bf16 backward reads: that one is recomputed)
-                    saved[key] = (x, d, mean, rstd, hpre, ln if (self.save_ln and ln.dtype == torch.bfloat16) else None)
+                if save:                         # (an e4m3 LayerNorm output / activation is not what the bf16 backward reads: those are recomputed)
+                    saved[key] = (x, d, mean, rstd, hpre, ln if (self.save_ln and ln.dtype == torch.bfloat16) else None,
+                                  g if (self.save_gelu and g.dtype == torch.bfloat16) else None)
                 del ln, g
                 x = xn
             if si < 3:
@@ -270,7 +284,7 @@ class ConvNextTower(nn.Module):
             for bi in range(self.depths[si] - 1, -1, -1):
                 blk = f[1 + 2 * si][bi]
                 key = f"{si}.{bi}"
-                x, d, mean, rstd, hpre, ln_saved = saved[key]
+                x, d, mean, rstd, hpre, ln_saved, g_saved = saved[key]
                 if hpre is None and key + ".bwdw" in wc and K.cnblock_bwdw_supported(C, d.shape[0]):
                     # stage 1: data path AND both weight gradients in two launches that read dx, d and write dd - the g / dh tensors
                     # ([M,4C] each) of the path below and its two weight-gradient GEMMs do not exist
@@ -294,8 +308,12 @@ class ConvNextTower(nn.Module):
                     L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
                     del ln, dh
                 else:
-                    g = torch.empty_like(hpre)             # GELU(hpre), rebuilt by the same epilogue that applies GELU'
-                    dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
+                    if g_saved is not None:                # the forward kept GELU(h): GELU' only (half the epilogue's arithmetic and stores)
+                        g = g_saved
+                        dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU_ONLY, aux_in=hpre)
+                    else:
+                        g = torch.empty_like(hpre)         # GELU(hpre), rebuilt by the same epilogue that applies GELU'
+                        dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)
                     L.gemm_tn_acc(dx, g, tmp[key + ".dw2raw"], colsum=tmp[key + ".db2raw"])
                     del g
                     ln = ln_saved if ln_saved is not None else \

@@ -163,9 +163,12 @@ def _run_experiment(comm, rank, world, tmpdir, global_loss=True):
     cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf",
                   [f"checkpoints.checkpoints_export_dir={tmpdir}", f"base.tensorboard_export_dir={tmpdir}",
                    "optimizer.config.learning_rate=0.05"] + ([] if global_loss else ["distributed.global_loss=false"]))
-    CE.model = _TinyClip
-    exp = create_experiment("classification")(config=cfg, train_dataloader=_experiment_batches(rank, world), valid_dataloader=None,
-                                              test_dataloader=None, tokenizer=None, comm=comm)
+    orig_model, CE.model = CE.model, _TinyClip
+    try:
+        exp = create_experiment("classification")(config=cfg, train_dataloader=_experiment_batches(rank, world), valid_dataloader=None,
+                                                  test_dataloader=None, tokenizer=None, comm=comm)
+    finally:
+        CE.model = orig_model          # (the 1-rank reference run shares the test process: do not leave the stand-in model behind)
     exp.criterion = _OracleClipLoss(comm if global_loss else None)
     losses = [exp.train(), exp.train(), exp.train()]       # epoch 1 runs at lr 0 (the reference's schedule), then it moves
     return exp, losses

@@ -64,6 +64,10 @@ def test_nt_epilogues(dev, M, N, K):
     assert y2.dtype == torch.bfloat16
     np.testing.assert_allclose(y2.float().cpu().numpy(), ((a.float() @ b.float().t()) * x.grad).cpu().numpy(), rtol=1e-2, atol=1e-2)
     np.testing.assert_allclose(act2.float().cpu().numpy(), torch.nn.functional.gelu(hh.float()).cpu().numpy(), rtol=1e-2, atol=1e-2)
+    # epilogue 5: GELU' alone (callers that kept GELU(h) from the forward) - bit-identical to epilogue 2's data gradient, fp32 and bf16
+    y5 = linalg.gemm_nt(a, b, epi=linalg.EPI_DGELU_ONLY, aux_in=hh, out_dtype=torch.float32)
+    assert torch.equal(y5, y)
+    assert torch.equal(linalg.gemm_nt(a, b, epi=linalg.EPI_DGELU_ONLY, aux_in=hh), y2)
     # ReLU pair
     y = linalg.gemm_nt(a, b, bias=bias, epi=linalg.EPI_RELU, out_dtype=torch.float32)
     np.testing.assert_allclose(y.cpu().numpy(), torch.relu(pre).cpu().numpy(), rtol=1e-4, atol=1e-3)

@@ -284,6 +284,12 @@ def test_fused_cnblock_mlp_forward_matches_unfused_reference(dev, C, M):
     ln_dev, _, _ = K.layernorm_fwd(d(xd), d(lnw), d(lnb), 1e-6, want_stats=False)
     assert torch.equal(y3, y) and torch.equal(hpre3, hpre)
     assert torch.allclose(xln.float(), ln_dev.float(), atol=2e-2, rtol=1e-2) and (xln != ln_dev).float().mean() < 0.02
+    # optional GELU(hidden) next to hpre, as the second GEMM consumed it (operand of that backward's dW2 GEMM): GELU of the fp32 hidden row,
+    # i.e. within one bf16 rounding of GELU(hpre)
+    outs = K.cnblock_mlp_fwd(d(xd), d(lnw), d(lnb), 1e-6, packed, d(b1), d(b2), d(gamma), d(res), want_hpre=True, want_stats=True, want_gact=True)
+    assert len(outs) == 5 and torch.equal(outs[0], y) and torch.equal(outs[1], hpre)
+    assert torch.allclose(outs[4].float().cpu(), F.gelu(h), atol=3e-2, rtol=2e-2)
+    assert torch.allclose(outs[4].float(), F.gelu(hpre.float()), atol=2e-2, rtol=1.2e-2)
 
 
 @pytest.mark.parametrize("C,M", [(96, 128 * 3 + 50), (128, 200), (192, 333), (384, 128 + 77)])

@@ -90,6 +90,29 @@ def test_convnext_stage1_on_chip_weight_gradient_backward_equals_the_gemm_path(d
     assert worst[0] < 2e-2 and min(_rel(grads["1"][0][n], g0)[1] for n, g0 in grads["0"][0].items()) > 0.9995, worst
 
 
+def test_convnext_backward_on_the_saved_activation_equals_the_rebuilt_one(dev, monkeypatch):
+    """Round 3: the stage-3/4 blocks (GEMM-pair backward) keep GELU(hidden) from the forward (mmg_cnblock_mlp_fwd's gact output / the first
+    GEMM's own output) and their data-gradient GEMM runs epilogue 5 (GELU' only).  MMG_SAVE_GELU=0 is the round-2 form (epilogue 2 rebuilds
+    the activation from the saved pre-activation): same forward bits, every parameter gradient equal to bf16 rounding noise."""
+    from mmgclip.networks.encoder import ConvNextTinyEncoder
+    img = torch.rand(3, 1, 64, 96, generator=torch.Generator().manual_seed(4))
+    wgt = torch.randn(3, 768, generator=torch.Generator().manual_seed(5))
+    runs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("MMG_SAVE_GELU", knob)
+        torch.manual_seed(0)
+        tower = ConvNextTinyEncoder(micro_batch=2)
+        _randomize(tower, 1)
+        tower = tower.to(dev)
+        feat = tower(img.to(dev))
+        assert tower.save_gelu == (knob == "1")
+        (feat * wgt.to(dev)).sum().backward()
+        runs[knob] = (feat.detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in tower.model.named_parameters()})
+    assert torch.equal(runs["1"][0], runs["0"][0])
+    worst = max((_rel(runs["1"][1][n], g0) + (n,) for n, g0 in runs["0"][1].items()), key=lambda t: t[0])
+    assert worst[0] < 2e-2 and min(_rel(runs["1"][1][n], g0)[1] for n, g0 in runs["0"][1].items()) > 0.9995, worst
+
+
 @pytest.mark.parametrize("variant,min_c", [("base", 1024), ("tiny", 768), ("base", 128), ("tiny", 384)])
 def test_convnext_fp8_forward_matches_the_fp8_oracle(dev, variant, min_c):
     """BASELINE config C5: e4m3 forward GEMMs (in every block with C % 128 == 0 and C >= min_c) against the oracle that rounds
