@@ -39,10 +39,10 @@ def test_layernorm_fwd_bwd(dev, M, C):
     _close(db, br.grad, 1e-3, 1e-3 * M ** 0.5)
 
 
-def test_layernorm_patchified(dev):
+@pytest.mark.parametrize("n,H,W,C", [(2, 8, 12, 96), (3, 6, 10, 192), (1, 4, 6, 384), (2, 4, 4, 64)])      # 64: the generic kernels
+def test_layernorm_patchified(dev, n, H, W, C):
     """LN writing the 2x2-patchified layout == LN then unfold(2,2) in (kh,kw,c) order."""
     from mmgclip import kernels as K
-    n, H, W, C = 2, 8, 12, 96
     x = _r((n * H * W, C), dev, 5).to(BF)
     gamma, beta = _r((C,), dev, 6).abs() + 0.5, _r((C,), dev, 7)
     y, mean, rstd = K.layernorm_fwd(x, gamma, beta, 1e-6, patch_hw=(H, W))
