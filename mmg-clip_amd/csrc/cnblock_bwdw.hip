@@ -106,6 +106,15 @@ MMG_API int mmg_debug_bwdw_probe(unsigned long long* out32, int reset) {
 // GEMM-equivalents per block) and no extra GELU work: GELU runs in launch 1, GELU' in launch 2.
 // NW = waves per workgroup: 8 (two per SIMD, 256 registers each) or 12 (three per SIMD, 168 registers: launch 1, whose register
 // needs allow it - a third wave per SIMD to fill the other two's waits).  A wave owns H4 / NW hidden units.
+// Lane id from the hardware, opaque to the optimiser: per-lane constants that are needed ONCE per tile (staging offsets, the row phase's row /
+// part) are re-derived from it at their use instead of living in registers for the whole kernel - launch 2 runs at 256 VGPRs and hipcc
+// had spilled nine of them, each reload sitting behind an `s_waitcnt vmcnt(0)` that also drained the prefetched rows and weight fragments.
+__device__ __forceinline__ int bw_fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 template <int C, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwArgs a) {
     typedef BwCfg<C> Cfg;
@@ -151,9 +160,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
 
     // ---- per-lane addresses -----------------------------------------------------------------------------------------------------
     // staging (P0): lanes 0-31 take d, lanes 32-63 take dy; 8 rows per wave, 4 lanes per row, 3 pieces of 16 bytes per lane
-    const int st_row = 16 * (wave & 3) + li, st_lg = lg;
-    const int st_lds = ((st_lg * RP) + 16 * (st_row >> 4) + bw_pos(st_row & 15)) * 16;         // + ks * 4 * RP * 16
-    const int st_off = (st_row * C + 8 * st_lg) * 2;                                           // bytes; + tile * R * C * 2 (scalar) + 64 * ks
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);                                   // (uniform: scalar register)
+    auto st_row_f = [&]() { return 16 * (wave_u & 3) + (bw_fresh_lane() & 15); };
+    auto st_lds_f = [&]() { const int l = bw_fresh_lane(), r = 16 * (wave_u & 3) + (l & 15); return (((l >> 4) * RP) + 16 * (r >> 4) + bw_pos(r & 15)) * 16; };   // + ks * 4 * RP * 16
+    auto st_off_f = [&]() { const int l = bw_fresh_lane(); return ((16 * (wave_u & 3) + (l & 15)) * C + 8 * (l >> 4)) * 2; };   // bytes; + tile * R * C * 2 (scalar) + 64 * ks
     // row-wise operand fragment (A of the C-deep products): row 16 rt + li, 16-byte column 4 ks + lg
     const int rd_row = (lg * RP + bw_pos(li)) * 16;                                            // + ks * 4 * RP * 16 + rt * 256
     // transposed reads of a row image: rows 4 lg + q of a 16-row tile, column piece p of a 16-column tile
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
 
     u32x4_t pre[KS];
     if (st_on && (int)blockIdx.x < a.ntiles) {
+        const int st_off = st_off_f();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off + 64 * ks, (int)blockIdx.x * (R * C * 2), 0);
     }
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
         // ================= P0: rows -> LDS images (xhat, dy), row statistics =======================================================
         {
             char* img = st_dy ? dyimg : ximg;
+            const int st_lds = st_lds_f();
             if (!st_on) {
             } else if (!st_dy) {
                 // (three passes over the 12 packed registers instead of 24 unpacked floats)
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
                 }
                 qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
                 const float rstd = rsqrtf(qq * (1.0f / C) + a.eps);
-                if (DX && st_lg == 0) { s_stat[(parity * R + st_row) * 2] = mean; s_stat[(parity * R + st_row) * 2 + 1] = rstd; }
+                if (DX && lg == 0) { const int st_row = st_row_f(); s_stat[(parity * R + st_row) * 2] = mean; s_stat[(parity * R + st_row) * 2 + 1] = rstd; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned w[4] = {pre[ks].x, pre[ks].y, pre[ks].z, pre[ks].w};
@@ -265,9 +277,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
         BWP_ADD(1, pr_p0, pr_a0); BWP_ADD(2, pr_a0, pr_a1);
         // next tile's rows: requested now, consumed at its P0
         if (st_on && tile + (int)gridDim.x < a.ntiles) {
+            const int st_off_n = st_off_f();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off + 64 * ks, (tile + (int)gridDim.x) * (R * C * 2), 0);
+                pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off_n + 64 * ks, (tile + (int)gridDim.x) * (R * C * 2), 0);
         }
 
         // ================= P1: this wave's 48 hidden units over the 64 rows ==========================================================
@@ -397,7 +410,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
             BWP_T(pr_c0);
             // P3's operands that live in the row images: this thread's 16 xhat values (row tid >> 3, columns 16 (tid & 7) ..), read now -
             // the next tile's P0 may overwrite the images as soon as the last wave has passed C2
-            const int p3_row = tid >> 3, p3_part = (tid & 7) < CT ? (tid & 7) : 0;
+            const int p3_tid = 64 * wave_u + bw_fresh_lane();
+            const int p3_row = p3_tid >> 3, p3_part = (p3_tid & 7) < CT ? (p3_tid & 7) : 0;
             const u32x4_t xq0 = *reinterpret_cast<const u32x4_t*>(ximg + ((2 * p3_part) * RP + 16 * (p3_row >> 4) + bw_pos(p3_row & 15)) * 16);
             const u32x4_t xq1 = *reinterpret_cast<const u32x4_t*>(ximg + ((2 * p3_part + 1) * RP + 16 * (p3_row >> 4) + bw_pos(p3_row & 15)) * 16);
             bw_barrier();                                                                                // C1: dh image has been read
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
             BWP_ADD(8, pr_b1, pr_c0); BWP_ADD(9, pr_c0, pr_c1); BWP_ADD(9, pr_c2, pr_c3);
 
             // ================= P3: LayerNorm backward, one row per 8 lanes (6 of them active, 16 columns each) =======================
-            const int row = p3_row, part = tid & 7;
+            const int row = p3_row, part = p3_tid & 7;
             const bool act = part < CT;
             const int c0 = act ? 16 * part : 0;
             const float rstd = s_stat[(parity * R + row) * 2 + 1];
