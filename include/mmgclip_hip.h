@@ -185,10 +185,7 @@ int mmg_dropout_bwd(const float* dy, const void* keep, float* dx, long long n, f
  * C % 32 == 0.  Replaces CNBlock.block[0] of torchvision ConvNeXt (mmgclip/networks/encoder.py:53). */
 int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, const void* add, void* y, int n, int H, int W,
                      int C, int flip, mmg_stream_t stream);
-/* Same contract on the matrix cores (one Toeplitz-operand MFMA per channel and kernel row; taps rounded to bf16), C % 32 == 0.
- * Kept for comparison: as fast as mmg_dwconv7_nhwc in the forward, not faster (csrc/dwconv7_mfma.hip). */
-int mmg_dwconv7_nhwc_mfma(const void* x, const float* w, const float* bias, const void* add, void* y, int n, int H, int W,
-                          int C, int flip, mmg_stream_t stream);
+/* (ABI 4: mmg_dwconv7_nhwc_mfma - the same contract as Toeplitz-operand MFMAs, measured at parity in rounds 1 - 2 - was removed.) */
 /* dw[49][C] += sum x(shifted) * dy ; dbias[C] += sum dy  (fp32, accumulated; dbias nullable) */
 int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int H, int W, int C,
                       mmg_stream_t stream);

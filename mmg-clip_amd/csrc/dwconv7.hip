@@ -451,20 +451,9 @@ static int dw_check(const char* who, int n, int H, int W, int C) {
 
 // y = dwconv7(x; w, bias) (+ add).  w is tap-major fp32 [49][C] (w[kh*7+kw][c] = weight[c,0,kh,kw]).
 // flip != 0 uses the taps reversed: with x := dy this is the gradient w.r.t. the input.
-int dwconv7_mfma_launch(const void* x, const float* w, const float* bias, const void* add, void* y, int n, int H, int W, int C,
-                        int flip, hipStream_t stream);      // dwconv7_mfma.hip
-
 MMG_API int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, const void* add, void* y, int n, int H,
                              int W, int C, int flip, hipStream_t stream) {
     MMG_CHECK_ARG(x && w && y, "mmg_dwconv7_nhwc: null pointer");
-    // MMG_DWCONV_MFMA=1 selects the matrix-core formulation (dwconv7_mfma.hip: correct, not faster yet); default is the fp32
-    // VALU kernel below
-    static const int use_mfma = getenv("MMG_DWCONV_MFMA") ? atoi(getenv("MMG_DWCONV_MFMA")) : 0;
-    if (use_mfma && n > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0) {
-        const int rc = dwconv7_mfma_launch(x, w, bias, add, y, n, H, W, C, flip, stream);
-        if (rc) mmg_set_error("mmg_dwconv7_nhwc: launch failed");
-        return rc;
-    }
     if (dw_check("mmg_dwconv7_nhwc", n, H, W, C)) return 1;
     const int tiles_w = cdiv(W, DW_TW), tiles_h = cdiv(H, DW_TH);
     const size_t shm = (size_t)DW_ROWS * DW_ROWD * 4 + 49 * DW_CB * 4;

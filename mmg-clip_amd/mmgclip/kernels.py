@@ -143,12 +143,12 @@ def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0)
          float(eps), float(wd), int(step), float(grad_scale), stream())
 
 
-def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None, mfma=False):
+def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None):
     y = out if out is not None else torch.empty(n * H * W, C, device=x.device, dtype=BF16)
     px = n * H * W * C
-    fam = "dwconv7_mfma_kernel" if mfma else ("dwconv7_rows2_kernel" if os.environ.get("MMG_DWCONV_ROWS2", "1") != "0" else "dwconv7_kernel")
+    fam = "dwconv7_rows2_kernel" if os.environ.get("MMG_DWCONV_ROWS2", "1") != "0" else "dwconv7_kernel"
     PROFILE.timed(fam, 98.0 * px, (6 if add is not None else 4) * px,
-                  lambda: call("mmg_dwconv7_nhwc_mfma" if mfma else "mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()),
+                  lambda: call("mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()),
                   f"n={n} {H}x{W} C={C}" + (" +add" if add is not None else ""))
     return y
 

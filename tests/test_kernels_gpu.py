@@ -136,11 +136,6 @@ def test_dwconv7(dev, n, H, W, C, monkeypatch):
     assert torch.equal(K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C), y)
     assert torch.equal(K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True), dx)
     monkeypatch.undo()
-    # the matrix-core formulation of the same two launches (Toeplitz-operand MFMAs, taps in bf16)
-    y2 = K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C, mfma=True)
-    _close(y2.reshape(n, H, W, C), ref.permute(0, 2, 3, 1), 1e-2, 3e-2)
-    dx2 = K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True, mfma=True)
-    _close(dx2.reshape(n, H, W, C), xr.grad.permute(0, 2, 3, 1) + res.float().reshape(n, H, W, C), 1e-2, 4e-2)
     for rows2, th in (("1", "8"), ("1", "16"), ("0", "8")):   # two dy rows per lane on 8- and 16-row tiles (defaults by size) / one
         monkeypatch.setenv("MMG_DWCONV_ROWS2", rows2)
         monkeypatch.setenv("MMG_DWG_TH", th)
