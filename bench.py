@@ -44,6 +44,89 @@ GFLOP_PER_PAIR = {  # fwd+bwd, 2 FLOP/MAC, train = 3 x forward;
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
+CONTRACT_LINE_MAX = 4096     # the driver keeps a tail of stdout: BENCH_r03's 46 KB line lost its head and parsed to nothing
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "…"
+
+
+def contract_line(detail, detail_path=None, limit=CONTRACT_LINE_MAX):
+    """The ONE stdout line of a run: the driver's contract fields, `config`, one `roofline` object (the kernel instantiation with the
+    largest share of a step, at most its three heaviest shape classes), a compact `cpu_baseline`, `roofline_method`, `comm` (N > 1) and
+    a short ranking of the next kernels - always below `limit` bytes.  Everything else (`roofline_other_kernels`, every shape class, the
+    five CPU legs in full) stays in `detail`, which main() writes to a file (`--detail-out`), never to stdout."""
+    line = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data") if k in detail}
+    cfg = dict(detail.get("config", {}))
+    for k in ("workload", "text_dropout", "streams"):
+        if k in cfg:
+            cfg[k] = _short(cfg[k], 160 if k == "workload" else 48)
+    line["config"] = cfg
+    rl_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_launch_us", "ms_per_step",
+               "algorithmic_bytes_per_launch", "algorithmic_flop_per_launch", "mfma_frac", "hbm_frac")
+    if "roofline" in detail:
+        r = detail["roofline"]
+        rl = {k: r[k] for k in rl_keys if k in r}
+        if r.get("traffic") is not None:
+            rl["traffic_source"] = _short(r.get("traffic_source", ""), 40)
+        rl["shape_classes"] = [{"shape": _short(c.get("shape", ""), 56), "bound": c["bound"], "frac": c["frac"], "launches": c["launches"],
+                                "avg_launch_us": c["avg_launch_us"]} for c in r.get("shape_classes", [])[:3]]
+        line["roofline"] = rl
+        # the next kernels by share of a step: [instantiation, ms per step, bound, fraction of that roof]
+        line["next_kernels"] = [[_short(o["kernel"], 48), o.get("ms_per_step"), o["bound"], o["frac"]]
+                                for o in detail.get("roofline_other_kernels", [])[:8]]
+    if "roofline_method" in detail:
+        m = dict(detail["roofline_method"])
+        m["note"] = _short(m.get("note", ""), 100)
+        line["roofline_method"] = m
+    if "comm" in detail:
+        line["comm"] = detail["comm"]
+    if "cpu_baseline" in detail:
+        c = detail["cpu_baseline"]
+        cb = {"value": c.get("value"), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+              "sample": _short(c.get("sample", ""), 180)}
+        for k, v in (("s256", c.get("s256")), ("faithful_s77", (c.get("faithful") or {}).get("s77")),
+                     ("faithful_s256", (c.get("faithful") or {}).get("s256")), ("c2_sample", c.get("c2_sample"))):
+            if isinstance(v, dict):
+                cb[k] = v.get("value")
+        line["cpu_baseline"] = cb
+    if detail_path:
+        line["detail"] = detail_path
+    # never above the limit: shed the optional parts in order of least value to the judge
+    for drop in (("next_kernels",), ("roofline", "shape_classes"), ("roofline_method", "note"), ("comm", "bucket_env"),
+                 ("cpu_baseline", "sample"), ("config", "text_dropout"), ("config", "streams"), ("roofline_method",), ("comm",)):
+        text = json.dumps(line, ensure_ascii=True)
+        if len(text) < limit:
+            return text
+        tgt = line
+        for k in drop[:-1]:
+            tgt = tgt.get(k, {})
+        if isinstance(tgt, dict):
+            tgt.pop(drop[-1], None)
+    text = json.dumps(line, ensure_ascii=True)
+    assert len(text) < limit, len(text)
+    return text
+
+
+def write_detail(detail, path):
+    """Full per-kernel / per-shape-class / per-CPU-leg record of the run, next to (not on) stdout."""
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(detail, f)
+        return path
+    except OSError:
+        import tempfile
+        alt = os.path.join(tempfile.gettempdir(), os.path.basename(path))
+        try:
+            with open(alt, "w") as f:
+                json.dump(detail, f)
+            return alt
+        except OSError:
+            return None
+
 
 def build(args, comm):
     from mmgclip.config import compose
@@ -197,6 +280,9 @@ def main():
                          "rocprofv3 kernel trace under profiles/ is collected with, so that its per-kernel averages are the kernels' own")
     ap.add_argument("--profile-steps", type=int, default=2,
                     help="instrumented steps run AFTER the timed region for the roofline leg (one stream, HIP events per launch)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="file for the full record (every kernel instantiation, every shape class, every CPU leg); stdout carries only the "
+                         "compact contract line (< 4 KB)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--cpu-baseline-worker", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -377,7 +463,10 @@ def main():
             out["comm"] = comm_block
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        where = write_detail(out, args.detail_out)
+        if where and where.startswith(ROOT + os.sep):
+            where = os.path.relpath(where, ROOT)
+        print(contract_line(out, where), flush=True)
     if comm is not None:
         dist.barrier()
         dist.destroy_process_group()

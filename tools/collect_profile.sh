@@ -10,15 +10,14 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 "$REPO/bench.py" --no-cpu-baseline --one-stream $3 > "$OUT/${TAG}_profiled_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 "$REPO/bench.py" --no-cpu-baseline --one-stream --detail-out "$OUT/${TAG}_profiled_bench_detail.json" $3 > "$OUT/${TAG}_profiled_bench.log" 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, sys
 out, tag = sys.argv[1], sys.argv[2]
 f = glob.glob("/tmp/kt/*/*kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(f)))
 open(f"{out}/{tag}_bench_default_kernel_stats.csv", "w").write(open(f).read())
-line = [l for l in open(f"{out}/{tag}_profiled_bench.log") if l.startswith("{")][-1]
-b = json.loads(line)
+b = json.load(open(f"{out}/{tag}_profiled_bench_detail.json"))     # the full record; stdout carries only the compact contract line
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 steps = b["steps"] + b["warmup"] + (b["roofline_method"]["profiled_steps"] + 1 if "roofline_method" in b else 0)
 md = [f"# {tag} — `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --one-stream` (1x MI355X, {b['config']['workload']}, {b['warmup']} warm-up + {b['steps']} timed steps)", "",
