@@ -65,6 +65,10 @@ struct BwArgs {
 // position of row r (0..15) inside its 16-row group of a row image: quads 0 and 1 exchanged (see the header)
 __device__ __forceinline__ int bw_pos(int r) { return r < 8 ? (r ^ 4) : r; }
 
+// scalar byte offset of a row tile for the buffer instructions: UNSIGNED arithmetic (tile * 12 288 passes 2^31 at M = 11.2 M rows; the
+// hardware reads soffset as unsigned, a signed product would be undefined behaviour), cast only at the builtin
+__device__ __forceinline__ int bw_soff(unsigned tile, unsigned bytes_per_tile) { return (int)(tile * bytes_per_tile); }
+
 __device__ __forceinline__ void bw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 typedef __attribute__((address_space(3))) bf16x4 bw_lds_v4;
@@ -115,12 +119,22 @@ __device__ __forceinline__ int bw_fresh_lane() {
     return l;
 }
 
-template <int C, int MODE, int NW>
+// VAR (round 4) selects the schedule of launch 1's P1 (launch 2: 0 only):
+//   0  round 3: weight fragments of every step re-read from L2 (3 KiB per wave and step: with the eight waves in lockstep that is
+//      24 KiB per step through the CU's 64 B/clk vector-memory path - the "load issue" segment of the phase probe), bias added at GELU time
+//   1  the wave's 9 W1 fragments (36 registers) and its three bias QUADS (the first product's C operand: no bias add) stay in
+//      registers for the whole launch; the bias-gradient column sums of dy only in the wave that keeps them
+//   2  = 1 + software pipeline: step st's GELU block is issued BETWEEN the six h products of step st + 1 and the six weight-gradient
+//      products of step st - 1 (sched_group_barrier: one MFMA per eight vector instructions), so the matrix pipe works under the
+//      vector stream of the same wave instead of alternating with it
+template <int C, int MODE, int NW, int VAR>
 __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwArgs a) {
     typedef BwCfg<C> Cfg;
     constexpr int H4 = Cfg::H4, KS = Cfg::KS, CT = Cfg::CT, RP = Cfg::RP, NP1 = Cfg::NP1, R = Cfg::R;
     constexpr int BW_THREADS = NW * 64, HS = H4 / NW, HT = HS / 16;
     static_assert(HS % 16 == 0 && (MODE == 1 || NW == 8), "hidden slice of a wave: whole 16-unit tiles; launch 2 is laid out for 8 waves");
+    static_assert(VAR == 0 || MODE == 1, "the resident-weight schedules are launch 1's");
+    constexpr bool RESW = VAR >= 1, PIPE = VAR >= 2;
     constexpr bool W2 = MODE == 1, DX = MODE == 2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
     if (st_on && (int)blockIdx.x < a.ntiles) {
         const int st_off = st_off_f();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off + 64 * ks, (int)blockIdx.x * (R * C * 2), 0);
+        for (int ks = 0; ks < KS; ++ks) pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off + 64 * ks, bw_soff(blockIdx.x, R * C * 2), 0);
     }
 
 #ifdef BW_PROBE
@@ -223,18 +237,32 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
             tT[ct] = bw_join(bw_tr(timg + off), bw_tr(timg + off + 256));
         }
     };
-    if ((int)blockIdx.x < a.ntiles) load_w(0);        // (the weight fragments of step 0: requested one tile ahead from here on)
-    int parity = 0;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
-        BWP_T(pr_p0);
-        if (W2) {                 // this tile's image pair
-            ximg = smem + Cfg::OFF_X + parity * (2 * Cfg::ROWIMG);
-            dyimg = ximg + Cfg::ROWIMG;
-            timg = dyimg;
+    bf16x8 w1r[RESW ? HT : 1][KS];                    // VAR >= 1: this wave's W1 gamma fragments, resident
+    f32x4 b1q[RESW ? HT : 1];                         //           and its bias as the first product's C operand
+    if constexpr (RESW) {
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                w1r[ht][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, w1g + (ht * KS + ks) * 1024, 0));
+            const float b = s_b1[HS * wave + 16 * ht + li];
+            b1q[ht] = f32x4{b, b, b, b};
         }
-        // ================= P0: rows -> LDS images (xhat, dy), row statistics =======================================================
-        {
-            char* img = st_dy ? dyimg : ximg;
+    } else if ((int)blockIdx.x < a.ntiles) load_w(0);        // (the weight fragments of step 0: requested one tile ahead from here on)
+    // bias gradient of the second linear = column sums of dy, taken from the transposed fragments of a row-tile pair: wave w < 6 keeps
+    // columns 16 w .. (uniform branches: only the wave that keeps a column tile unpacks it)
+    auto dy_colsum = [&]() {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            if (ct == wave_u) {
+                float sy = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sy += bf2f((bf16_t)tT[ct][e]);
+                bacc[0] += sy;
+            }
+    };
+    auto stage_rows = [&](char* ximg_s, char* dyimg_s, int par_s) {
+            char* img = st_dy ? dyimg_s : ximg_s;
             const int st_lds = st_lds_f();
             if (!st_on) {
             } else if (!st_dy) {
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
                 }
                 qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
                 const float rstd = rsqrtf(qq * (1.0f / C) + a.eps);
-                if (DX && lg == 0) { const int st_row = st_row_f(); s_stat[(parity * R + st_row) * 2] = mean; s_stat[(parity * R + st_row) * 2 + 1] = rstd; }
+                if (DX && lg == 0) { const int st_row = st_row_f(); s_stat[(par_s * R + st_row) * 2] = mean; s_stat[(par_s * R + st_row) * 2 + 1] = rstd; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const unsigned w[4] = {pre[ks].x, pre[ks].y, pre[ks].z, pre[ks].w};
@@ -270,7 +298,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) *reinterpret_cast<u32x4_t*>(img + st_lds + ks * (4 * RP * 16)) = pre[ks];
             }
+    };
+    int parity = 0;
+    if constexpr (W2 && RESW) {          // the first tile's rows
+        if ((int)blockIdx.x < a.ntiles) stage_rows(smem + Cfg::OFF_X, smem + Cfg::OFF_X + Cfg::ROWIMG, 0);
+    }
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, parity ^= 1) {
+        BWP_T(pr_p0);
+        if (W2) {                 // this tile's image pair
+            ximg = smem + Cfg::OFF_X + parity * (2 * Cfg::ROWIMG);
+            dyimg = ximg + Cfg::ROWIMG;
+            timg = dyimg;
         }
+        // ================= P0: rows -> LDS images (xhat, dy), row statistics =======================================================
+        // (VAR >= 1, launch 1: this tile's images were written in the MIDDLE of the previous tile's P1 - see there; the first tile's before the loop)
+        if (!(W2 && RESW)) stage_rows(ximg, dyimg, parity);
         BWP_T(pr_a0);
         bw_barrier();                                                                                    // A
         BWP_T(pr_a1);
@@ -280,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
             const int st_off_n = st_off_f();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off_n + 64 * ks, (tile + (int)gridDim.x) * (R * C * 2), 0);
+                pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off_n + 64 * ks, bw_soff((unsigned)tile + gridDim.x, R * C * 2), 0);
         }
 
         // ================= P1: this wave's 48 hidden units over the 64 rows ==========================================================
@@ -290,30 +332,100 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
         //   row fragments (xhat, dy rows of this rp)   once per rp, loaded after the last product of the previous rp
         //   transposed fragments (k = rows)            once per rp, loaded after the last weight-gradient product of the previous rp
         //   weight fragments of the next step          requested from L2 right after this step's products, landing under the GELU block
+        if constexpr (PIPE) {
+            // ---- launch 1, VAR 2: one-step software pipeline.  Program order of step st: the six weight-gradient products of step
+            // st - 1 (operand: the g fragment kept from it), the six h products of step st + 1 (C operand = the bias quad), then step
+            // st's GELU block; sched_group_barrier spreads the twelve MFMAs one per seven vector instructions, so that the matrix pipe
+            // runs under this wave's own vector stream.  Row fragments of the next rp are requested at the top of the step that issues
+            // its first h products; the transposed fragments of rp 1 after the last weight-gradient product of rp 0 has been issued.
+            load_a(0); load_t(0);
+            f32x4 hb[2][2];
+            bf16x8 ofp = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            auto h_prod = [&](int ht_n, f32x4 (&h)[2]) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+                        h[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[ks][t2], w1r[RESW ? ht_n : 0][ks], ks == 0 ? b1q[RESW ? ht_n : 0] : h[t2], 0, 0, 0);
+            };
+            h_prod(0, hb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 2 * HT; ++st) {
+                const int rp = st / HT, ht = st % HT;
+                if constexpr (W2 && RESW) {
+                    // the NEXT tile's rows (requested after barrier A, 3 steps ago) go into the other image pair here, in the middle of this
+                    // tile's P1: the LayerNorm statistics of waves 0-3 run beside their SIMD partners' GELU blocks instead of in front of a
+                    // barrier every wave waits at (phase probe, round 3: P0 + wait A = 15 % of the launch).  Legal without another barrier:
+                    // that pair was last read in the previous tile's P1, which every wave left before it passed this tile's barrier A.
+                    if (st == HT && tile + (int)gridDim.x < a.ntiles) {
+                        char* nx = smem + Cfg::OFF_X + (parity ^ 1) * (2 * Cfg::ROWIMG);
+                        stage_rows(nx, nx + Cfg::ROWIMG, parity ^ 1);
+                    }
+                }
+                if (st == 0 || st == HT + 1) dy_colsum();                       // (tT holds rp 0 / rp 1 from here: rp 1 is requested at the end of step HT)
+                if (ht == HT - 1 && rp == 0) load_a(1);                         // xa of rp 0: last read by the h products issued in the previous step
+                __builtin_amdgcn_sched_barrier(0);
+                if (st > 0) {                                                   // weight gradient of step st - 1
+                    const int htp = (st - 1) % HT;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) wacc[htp][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[ct], ofp, wacc[htp][ct], 0, 0, 0);
+                }
+                if (st + 1 < 2 * HT) h_prod((st + 1) % HT, hb[(st + 1) & 1]);
+                unsigned op[4];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_bf16(hb[st & 1][t2][e]);
+                    op[2 * t2] = pack2bf(v[0], v[1]); op[2 * t2 + 1] = pack2bf(v[2], v[3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);          // seven VALU
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ofp = __builtin_bit_cast(bf16x8, (u32x4_t{op[0], op[1], op[2], op[3]}));
+                if (st == HT) load_t(1);                                        // rp 0's last weight-gradient product was issued above
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wacc[HT - 1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[ct], ofp, wacc[HT - 1][ct], 0, 0, 0);
+        } else
         {
             load_a(0); load_t(0);
             float dbsum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 2 * HT; ++st) {
                 const int rp = st / HT, ht = st % HT;
-                const float bias = s_b1[HS * wave + 16 * ht + li];
+                if constexpr (W2 && RESW) {
+                    // the NEXT tile's rows (requested after barrier A, 3 steps ago) go into the other image pair here, in the middle of this
+                    // tile's P1: the LayerNorm statistics of waves 0-3 run beside their SIMD partners' GELU blocks instead of in front of a
+                    // barrier every wave waits at (phase probe, round 3: P0 + wait A = 15 % of the launch).  Legal without another barrier:
+                    // that pair was last read in the previous tile's P1, which every wave left before it passed this tile's barrier A.
+                    if (st == HT && tile + (int)gridDim.x < a.ntiles) {
+                        char* nx = smem + Cfg::OFF_X + (parity ^ 1) * (2 * Cfg::ROWIMG);
+                        stage_rows(nx, nx + Cfg::ROWIMG, parity ^ 1);
+                    }
+                }
+                const float bias = RESW ? 0.f : s_b1[HS * wave + 16 * ht + li];     // (VAR >= 1: the bias is the products' C operand)
                 f32x4 hacc[2], gacc[2];
                 BWP_T(pr_s0);
 #pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) { hacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; gacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int t2 = 0; t2 < 2; ++t2) { hacc[t2] = RESW ? b1q[RESW ? ht : 0] : f32x4{0.f, 0.f, 0.f, 0.f}; gacc[t2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
-                        hacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[ks][t2], w1f[ks], hacc[t2], 0, 0, 0);
+                        hacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[ks][t2], RESW ? w1r[RESW ? ht : 0][ks] : w1f[ks], hacc[t2], 0, 0, 0);
                         if (DX) gacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[ks][t2], w2f[ks], gacc[t2], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 BWP_T(pr_s1);
                 if (st + 1 == 2 * HT) {
-                    if (tile + (int)gridDim.x < a.ntiles) load_w(0);      // next tile's first step: in flight over P2 / P3 / P0
+                    if (!RESW && tile + (int)gridDim.x < a.ntiles) load_w(0);      // next tile's first step: in flight over P2 / P3 / P0
                 } else {
-                    load_w((st + 1) % HT);
+                    if (!RESW) load_w((st + 1) % HT);
                     if (W2 && ht == HT - 1) load_a(rp + 1);      // launch 1 keeps the row fragments of an rp for its three steps
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -325,7 +437,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (W2) v[e] = gelu_bf16(hacc[t2][e] + bias);
+                        if (W2) v[e] = gelu_bf16(RESW ? hacc[t2][e] : hacc[t2][e] + bias);
                         else { v[e] = gacc[t2][e] * gelu_bf16_grad_poly(hacc[t2][e] + bias); dbsum[ht] += v[e]; }
                     }
                     op[2 * t2] = pack2bf(v[0], v[1]); op[2 * t2 + 1] = pack2bf(v[2], v[3]);
@@ -344,12 +456,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
                     else wacc[ht][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, tT[ct], wacc[ht][ct], 0, 0, 0);        // D[hidden][c]
                 }
                 if (W2 && ht == 0) {          // bias gradient of the second linear: column sums of dy; wave w < 6 keeps columns 16 w ..
+                    if constexpr (RESW) dy_colsum();
+                    else {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        float sy = 0.f;
+                        for (int ct = 0; ct < CT; ++ct) {
+                            float sy = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) sy += bf2f((bf16_t)tT[ct][e]);
-                        bacc[0] += (ct == wave) ? sy : 0.f;
+                            for (int e = 0; e < 8; ++e) sy += bf2f((bf16_t)tT[ct][e]);
+                            bacc[0] += (ct == wave) ? sy : 0.f;
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -455,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         o[e] = pack2bf(rstd * (fmaf(-x[8 * h8 + 2 * e], m2, gv[8 * h8 + 2 * e]) - m1), rstd * (fmaf(-x[8 * h8 + 2 * e + 1], m2, gv[8 * h8 + 2 * e + 1]) - m1));
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, rs_dd, (row * C + c0 + 8 * h8) * 2, tile * (R * C * 2), 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o[0], o[1], o[2], o[3]}, rs_dd, (row * C + c0 + 8 * h8) * 2, bw_soff((unsigned)tile, R * C * 2), 0);
                 }
             }
             // (no barrier: the next P0 writes the row images and the other parity of s_stat; s_dln is rewritten as the dh image only
@@ -553,15 +668,8 @@ __global__ __launch_bounds__(256) void cnblock_bwdw_pack_kernel(const BwPack a) 
     }
 }
 
-static int bw_cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t pr;
-        (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    }
-    return cus;
-}
+#define BW_DEFAULT_VAR 2
+static int bw_cu_count() { return mmg_cu_count_cached(); }
 
 MMG_API int mmg_cnblock_bwdw_supported(int C) { return C == 96 ? 1 : 0; }
 MMG_API long long mmg_cnblock_bwdw_packed_elems(int C) { return C == 96 ? (long long)BwCfg<96>::PK_TOTAL : 0; }
@@ -594,13 +702,26 @@ MMG_API int mmg_cnblock_bwdw(const void* dy, const void* xd, const float* ln_w, 
     // launch 1 with 12 waves (three per SIMD, 168 registers): same-box A/B at 16.8 M rows, two runs each: 13.10 / 13.15 ms against
     // 12.94 / 13.09 with 8 waves - the launch is bound by VALU issue (GELU), not by latency, so the third wave buys nothing.  Off.
     static const int w12 = getenv("MMG_BWDW_W12") ? atoi(getenv("MMG_BWDW_W12")) : 0;
-    mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 8>, BwCfg<96>::LDS);
-    mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 12>, BwCfg<96>::LDS);
-    mmg_allow_lds(cnblock_bwdw_kernel<96, 2, 8>, BwCfg<96>::LDS);
+    // schedule of launch 1 (see the kernel's VAR comment); MMG_BWDW_VAR = 0 / 1 / 2 for same-process A/B runs (tools/bwdw_bench.py)
+    const char* ev = getenv("MMG_BWDW_VAR");
+    const int var = ev ? atoi(ev) : BW_DEFAULT_VAR;
+    typedef BwCfg<96> Cfg;
     MMG_NOTE_KERNEL("cnblock_bwdw_kernel<96, *>");
-    if (w12) hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 12>), dim3(grid), dim3(768), BwCfg<96>::LDS, stream, a);
-    else hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 8>), dim3(grid), dim3(512), BwCfg<96>::LDS, stream, a);
-    hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 2, 8>), dim3(grid), dim3(512), BwCfg<96>::LDS, stream, a);
+    if (w12) {
+        mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 12, 0>, Cfg::LDS);
+        hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 12, 0>), dim3(grid), dim3(768), Cfg::LDS, stream, a);
+    } else if (var == 2) {
+        mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 8, 2>, Cfg::LDS);
+        hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 8, 2>), dim3(grid), dim3(512), Cfg::LDS, stream, a);
+    } else if (var == 1) {
+        mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 8, 1>, Cfg::LDS);
+        hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 8, 1>), dim3(grid), dim3(512), Cfg::LDS, stream, a);
+    } else {
+        mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 8, 0>, Cfg::LDS);
+        hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 8, 0>), dim3(grid), dim3(512), Cfg::LDS, stream, a);
+    }
+    mmg_allow_lds(cnblock_bwdw_kernel<96, 2, 8, 0>, Cfg::LDS);
+    hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 2, 8, 0>), dim3(grid), dim3(512), Cfg::LDS, stream, a);
     MMG_LAUNCH_CHECK("mmg_cnblock_bwdw");
     return 0;
 }

@@ -117,21 +117,30 @@ MMG_API int mmg_debug_mlp_probe(unsigned long long* out8, int reset) {
 #endif
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
-template <int C, bool SAVE>
-__global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_mlp_fwd_kernel(const MlpFwd p) {
-    constexpr int NC = MlpCfg<C>::NC, MT = MlpCfg<C>::MT, MLP_THREADS = MlpCfg<C>::THREADS, MLP_BM = MlpCfg<C>::BM;
+// RW > 0 (round 4, C = 96 only: both weight matrices are 2 x 72 KiB = 144 KiB, they FIT the CU's 160 KiB of LDS): the "resident"
+// form.  ONE workgroup of RW waves per CU stages all 4C / NC chunk images once, in its prologue; after that single barrier the waves
+// never meet again - no per-chunk DMA stream (the streaming form moves the whole 144 KiB from L2 into LDS for every 128 rows: two
+// thirds of the bytes entering the CU), no per-chunk `vmcnt(0)` + barrier, and each wave walks its own 32-row tiles (tile index by
+// wave, not by workgroup), so the waves of a SIMD drift apart and one wave's GELU block runs beside another's MFMAs.
+template <int C, bool SAVE, int RW = 0>
+__global__ __launch_bounds__(RW ? RW * 64 : MlpCfg<C>::THREADS, RW ? RW / 4 : MlpCfg<C>::WGS) void cnblock_mlp_fwd_kernel(const MlpFwd p) {
+    constexpr bool RES = RW > 0;
+    constexpr int NC = MlpCfg<C>::NC, MT = MlpCfg<C>::MT, MLP_THREADS = RES ? RW * 64 : MlpCfg<C>::THREADS;
+    constexpr int MLP_BM = RES ? 16 * MT : MlpCfg<C>::BM;        // (resident form: `tile` counts 32-row WAVE tiles)
     constexpr int KS1 = C / 32, CT = C / 16, NSUB = NC / 32, NCH = 4 * C / NC;
     constexpr int PART = NC * C * 2, CHUNK = 2 * PART, LOADS = CHUNK / 16 / MLP_THREADS;
     static_assert(CHUNK % (16 * MLP_THREADS) == 0, "chunk must be a whole number of 16-byte granules per thread");
     static_assert(NCH % 2 == 0, "ring parity is carried across tiles");
+    static_assert(!RES || (!SAVE && NCH * CHUNK + 8 * C * 4 <= 160 * 1024), "resident form: every chunk image in LDS, nothing saved");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_lnw = reinterpret_cast<float*>(smem + 2 * CHUNK);   // [C] [C] [4C] [C] [C]
+    float* s_lnw = reinterpret_cast<float*>(smem + (RES ? NCH : 2) * CHUNK);   // [C] [C] [4C] [C] [C]
     float* s_lnb = s_lnw + C;
     float* s_b1 = s_lnb + C;
     float* s_b2 = s_b1 + 4 * C;
     float* s_gm = s_b2 + C;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = RES ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;      // (resident form: the tile index is per wave - keep it scalar)
     const int li = lane & 15, lg = lane >> 4;
     char* lds_wave = smem + (tid & ~63) * 16;
     const char* wsrc = reinterpret_cast<const char*>(p.wt) + tid * 16;
@@ -141,19 +150,23 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
 #pragma unroll
         for (int it = 0; it < LOADS; ++it) mlp_glds16(s + it * (MLP_THREADS * 16), lds_wave + buf * CHUNK + it * (MLP_THREADS * 16));
     };
-    if ((int)blockIdx.x < p.ntiles) stage(0, 0);
+    if constexpr (RES) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) stage(ch, ch);
+    } else if ((int)blockIdx.x < p.ntiles) stage(0, 0);
     for (int i = tid; i < C; i += MLP_THREADS) {
         s_lnw[i] = p.ln_w[i]; s_lnb[i] = p.ln_b[i]; s_b2[i] = p.b2[i]; s_gm[i] = p.gamma[i];
     }
     for (int i = tid; i < 4 * C; i += MLP_THREADS) s_b1[i] = p.b1[i];
+    if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
 #ifdef MLP_PROBE
     long long pr_wait = 0, pr_g1 = 0, pr_gelu = 0, pr_g2 = 0;
 #endif
     PROBE_T(pr_start);
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const long row0 = (long)tile * MLP_BM + wave * (16 * MT) + li;          // + 16*mi
+    for (int tile = RES ? (int)blockIdx.x * RW + wave : (int)blockIdx.x; tile < p.ntiles; tile += RES ? (int)gridDim.x * RW : (int)gridDim.x) {
+        const long row0 = RES ? (long)tile * MLP_BM + li : (long)tile * MLP_BM + wave * (16 * MT) + li;          // + 16*mi
         // ---- rows of d -> LayerNorm -> bf16 B-operand fragments ---------------------------------------------------------
         bf16x8 xf[MT][KS1];
 #pragma unroll
@@ -212,13 +225,17 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS) void cnblock_ml
         // ---- hidden chunks ---------------------------------------------------------------------------------------------
         for (int ch = 0; ch < NCH; ++ch) {
             PROBE_T(pr_a);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!RES) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             PROBE_T(pr_b);
             PROBE_ADD(pr_wait, pr_a, pr_b);
-            if (ch + 1 < NCH) stage((ch + 1) & 1, ch + 1);
-            else if (tile + (int)gridDim.x < p.ntiles) stage(0, 0);
-            const char* wb = smem + (ch & 1) * CHUNK;
+            if constexpr (!RES) {
+                if (ch + 1 < NCH) stage((ch + 1) & 1, ch + 1);
+                else if (tile + (int)gridDim.x < p.ntiles) stage(0, 0);
+            }
+            const char* wb = smem + (RES ? ch : (ch & 1)) * CHUNK;
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
 #if defined(MLP_PROBE) && MLP_PROBE >= 2
@@ -596,15 +613,8 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
     }
 }
 
-static int mlp_cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t pr;
-        (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    }
-    return cus;
-}
+#define MLP_FWD_RES_DEFAULT 12
+static int mlp_cu_count() { return mmg_cu_count_cached(); }
 
 // The backward's 4C-wide outputs (g, dh) beyond the 256 MiB Infinity Cache are consumed much later by the weight-gradient GEMMs:
 // stored past L2 (nontemporal) from C = 128 up.  Same-run A/B (profiles/r02_mlp_nt_store_ab.txt): backward -8...-17 % at C = 192,
@@ -644,6 +654,27 @@ static int launch_mlp_fwd(MlpFwd p, hipStream_t stream) {
     p.ntiles = (int)((p.M + Cfg::BM - 1) / Cfg::BM);
     const int cap = Cfg::WGS * mlp_cu_count();
     const int grid = p.ntiles < cap ? p.ntiles : cap;
+    if constexpr (C == 96) {
+        // resident weights (see the kernel): MMG_MLP_FWD_RES = waves per workgroup (8 / 12; 0 = the streaming form), read per call
+        const char* e = getenv("MMG_MLP_FWD_RES");
+        const int rw = e ? atoi(e) : MLP_FWD_RES_DEFAULT;
+        if (!p.hpre && (rw == 8 || rw == 12)) {
+            const size_t ldsr = (size_t)(4 * C / Cfg::NC) * (2 * Cfg::NC * C * 2) + (size_t)8 * C * sizeof(float);
+            p.ntiles = (int)((p.M + 16 * Cfg::MT - 1) / (16 * Cfg::MT));          // 32-row wave tiles
+            const int cus = mlp_cu_count();
+            const int gridr = (p.ntiles + rw - 1) / rw < cus ? (p.ntiles + rw - 1) / rw : cus;
+            MMG_NOTE_KERNEL("cnblock_mlp_fwd_kernel<%d, false, %d>", C, rw);
+            if (rw == 12) {
+                mmg_allow_lds(cnblock_mlp_fwd_kernel<C, false, 12>, ldsr);
+                hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, false, 12>), dim3(gridr), dim3(768), ldsr, stream, p);
+            } else {
+                mmg_allow_lds(cnblock_mlp_fwd_kernel<C, false, 8>, ldsr);
+                hipLaunchKernelGGL((cnblock_mlp_fwd_kernel<C, false, 8>), dim3(gridr), dim3(512), ldsr, stream, p);
+            }
+            MMG_LAUNCH_CHECK("mmg_cnblock_mlp_fwd");
+            return 0;
+        }
+    }
     MMG_NOTE_KERNEL("cnblock_mlp_fwd_kernel<%d, %s>", C, p.hpre ? "true" : "false");
     if (p.hpre) {
         mmg_allow_lds(cnblock_mlp_fwd_kernel<C, true>, lds);

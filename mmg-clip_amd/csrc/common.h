@@ -23,6 +23,7 @@ void mmg_set_error(const char* fmt, ...);
 // diagnostics (core.hip): the dispatchers record the name of the kernel instantiation they launch while notes are on
 int mmg_kernel_notes_on(void);
 void mmg_note_kernel(const char* fmt, ...);
+int mmg_cu_count_cached(void);        // CUs of the current device, cached per device id (core.hip)
 #define MMG_NOTE_KERNEL(...) do { if (mmg_kernel_notes_on()) mmg_note_kernel(__VA_ARGS__); } while (0)
 #define MMG_CHECK_ARG(cond, ...)                 \
     do {                                         \

@@ -29,6 +29,21 @@ MMG_API int mmg_abi_version(void) { return 4; }
 MMG_API const char* mmg_last_error(void) { return g_err; }
 MMG_API const char* mmg_target_arch(void) { return "gfx950"; }
 
+// CU count of the CURRENT device, cached per device id (persistent grids are sized by it on every launch; a process that drives
+// several devices, or partitions of different sizes, gets each device's own count - ADVICE r3).  256 when the query fails.
+int mmg_cu_count_cached(void) {
+    static int cus[64];                       // 0 = not asked yet; racing first calls store the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int c = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (!c) {
+        hipDeviceProp_t pr;
+        c = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        __atomic_store_n(&cus[dev], c, __ATOMIC_RELAXED);
+    }
+    return c;
+}
+
 // Number of compute units of the current device (used to size persistent grids); <0 on failure.
 MMG_API int mmg_device_cu_count(void) {
     int dev = 0;

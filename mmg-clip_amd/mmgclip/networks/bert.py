@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
-from ..params import ParamArena, backward_finished, last_backward, note_forward
+from ..params import ParamArena, backward_finished, last_backward, note_forward, stream_anchor
 
 
 class BertConfigLite:
@@ -378,7 +378,7 @@ class BertTower(nn.Module):
         use_packed = self.packed if packed is None else bool(packed)
         lens = self._lengths_of(attention_mask) if (use_packed and attention_mask is not None and ids.shape[1] <= 256) else None
         note_forward(self, needs_grad)
-        return _BertFn.apply(self, ids, tt, mask, self._anchor if needs_grad else None, lens)
+        return _BertFn.apply(self, ids, tt, mask, stream_anchor(self, self._anchor.device) if needs_grad else None, lens)
 
 
 class _BertFn(torch.autograd.Function):

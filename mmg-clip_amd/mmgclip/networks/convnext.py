@@ -26,7 +26,7 @@ import torch.nn as nn
 from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
-from ..params import ParamArena, backward_finished, last_backward, note_forward
+from ..params import ParamArena, backward_finished, last_backward, note_forward, stream_anchor
 
 CONFIGS = {
     "tiny": dict(depths=(3, 3, 9, 3), dims=(96, 192, 384, 768)),
@@ -401,7 +401,7 @@ class ConvNextTower(nn.Module):
             raise NotImplementedError("training the ConvNeXt tower needs H and W to be multiples of 32 (inference accepts any "
                                       "size >= 32: strided layers drop the remainder exactly as torch's convolutions do)")
         note_forward(self, needs_grad)
-        return _ConvNextFn.apply(self, images.float().contiguous(), self._anchor if needs_grad else None)
+        return _ConvNextFn.apply(self, images.float().contiguous(), stream_anchor(self, self._anchor.device) if needs_grad else None)
 
 
 class _ConvNextFn(torch.autograd.Function):

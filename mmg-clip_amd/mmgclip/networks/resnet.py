@@ -17,7 +17,7 @@ import torch.nn as nn
 from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
-from ..params import ParamArena, backward_finished, note_forward
+from ..params import ParamArena, backward_finished, note_forward, stream_anchor
 from .._hip import call, ptr, stream
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -212,7 +212,7 @@ class ResNetTower(nn.Module):
         self._materialize(x.device)
         needs_grad = torch.is_grad_enabled() and self.training and self._arena.any_trainable()
         note_forward(self, needs_grad)
-        return _ResNetFn.apply(self, x.float().contiguous(), self._anchor if needs_grad else None)
+        return _ResNetFn.apply(self, x.float().contiguous(), stream_anchor(self, self._anchor.device) if needs_grad else None)
 
 
 class _ResNetFn(torch.autograd.Function):

@@ -17,7 +17,7 @@ from .. import _hip
 from .. import kernels as K
 from .. import linalg as L
 from .._hip import call, ptr, stream
-from ..params import ParamArena, backward_finished, note_forward
+from ..params import ParamArena, backward_finished, note_forward, stream_anchor
 
 LN_EPS = 1e-6
 
@@ -188,7 +188,7 @@ class ViTTower(nn.Module):
         self._materialize(images.device)
         needs_grad = torch.is_grad_enabled() and self._arena.any_trainable()
         note_forward(self, needs_grad)
-        return _ViTFn.apply(self, images.float().contiguous(), self._anchor if needs_grad else None)
+        return _ViTFn.apply(self, images.float().contiguous(), stream_anchor(self, self._anchor.device) if needs_grad else None)
 
 
 class _ViTFn(torch.autograd.Function):

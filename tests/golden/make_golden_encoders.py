@@ -284,6 +284,10 @@ def golden_c1(proj_mod, losses_mod, S, seed=61, min_len=None, tag=""):
 
 def main(proj_mod=None, losses_mod=None):
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    if proj_mod is not None and "--only-c1" in sys.argv:      # round 4: the two first C1 fixtures alone (they predated the `min_len` key)
+        golden_c1(proj_mod, losses_mod, 77)
+        golden_c1(proj_mod, losses_mod, 256)
+        return
     golden_convnext("g5_convnext_tiny.npz", (3, 3, 9, 3), (96, 192, 384, 768), 1, 2, 96, 64, seed=11)
     golden_convnext("g5_convnext_small.npz", (2, 2, 2, 2), (32, 64, 128, 256), 3, 2, 77, 50, seed=21)
     golden_vit()

@@ -17,6 +17,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 import recipes as R                                                  # noqa: E402
+from tests.conftest import measured                                  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 CFG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmg-clip_amd", "configs")
@@ -125,6 +126,11 @@ def test_c1_training_step_matches_golden(dev, golden_dir, S):
     model, batch = build_c1_model(g)
     e = c1_errors(model, batch, g)
     print(f"\nC1 S={S} HIP vs third-party/reference golden: " + ", ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in e.items()))
+    # every figure of the run goes to gpurun_out/measured_tolerances.jsonl (committed copy: profiles/rNN_measured_tolerances.jsonl), the
+    # per-tower error budget of the loss (loss_rel_*_tower_only) included, for all three batches
+    measured(f"c1_training_step_S={S}", **{k: v for k, v in e.items() if isinstance(v, float)},
+             image_grad_worst_rel=e["image_grad_worst"][0], image_grad_min_cos=e["image_grad_worst"][1], image_grad_worst_name=e["image_grad_worst"][2],
+             text_grad_worst_rel=e["text_grad_worst"][0], text_grad_min_cos=e["text_grad_worst"][1], text_grad_worst_name=e["text_grad_worst"][2])
     # north_star: "loss matching reference to 1e-3 rel".  Error budget (loss recomputed with one tower's embeddings taken from the
     # golden): the text tower owns it - with a bf16 residual stream 9e-4 ... 1.1e-3 of the 1.0e-3 ... 1.05e-3 total, the image tower
     # 1.4e-4 ... 1.7e-4.  With the fp32 stream of networks/bert.py: total 6.6e-4 (S = 77) / 3.2e-4 (S = 256), logits 7e-3 / 1e-2.
@@ -139,6 +145,8 @@ def test_c1_training_step_matches_golden(dev, golden_dir, S):
     # encoder.layer.11.attention.self.query.bias - a tensor BELOW the floor (only the 8 [SEP] queries of the last layer feed the loss, and
     # over 128...256 keys their dS = P o (dP - delta) is a difference of nearly equal bf16-rounded numbers): its error is 0.7 % of the
     # tower's median gradient norm, against 0.2 % at S = 77; every tensor above the floor keeps cosine >= 0.999 (measured 0.9992).
+    # The 0.5 bar of that fixture was written FROM that measurement (0.34 in the round-3 run, profiles/r03_measured_tolerances.jsonl; the
+    # round-4 figure is in profiles/r04_measured_tolerances.jsonl): it bounds noise on a below-floor tensor, it is not a parity claim.
     text_bar = 0.5 if str(S).endswith("_long") else 0.15
     assert e["text_grad_worst"][0] <= text_bar and e["text_grad_worst"][1] >= 0.99, e
     assert e["d_word_rows_rel"] <= 5e-2, e

@@ -228,3 +228,37 @@ def test_config_c3_two_ranks_global_batch_and_both_gradient_sync_modes(dev):
         c = over[4]["comm"]
         assert c["all_gather_calls"] == 4 and c["all_gather_bytes"] == 2 * (2 * 4 * 512 * 4) + 2 * (2 * 4 * 4)   # embeddings + LSE vectors
     assert np.array_equal(results[0][2][1], results[1][2][1]) and np.array_equal(results[0][3][2], results[1][3][2])
+
+
+def test_bench_two_ranks_prints_one_compact_line_with_comm(dev, tmp_path):
+    """bench.py exactly as the driver launches it at N = 2 (torch.distributed.run, one rank per process; gloo transport because the
+    test box has one GPU, which both ranks share): rank 0 prints ONE JSON line below 4 KB that parses, carries the contract fields
+    for N = 2 and a populated `comm` block; the full per-kernel record goes to --detail-out (VERDICT r3 next #1 / #7)."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    detail = str(tmp_path / "bench_detail.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--image-size", "224", "--micro-batch", "8", "--backend", "gloo", "--profile-steps", "1", "--detail-out", detail]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["higher_is_better"]) == (2, 2, 1, "weak", True)
+    assert d["value"] > 0 and abs(d["value"] - 16 * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2" and d["config"]["loss_scope"].startswith("global")
+    c = d["comm"]
+    assert c["mode"].startswith("bucketed") and c["grad_allreduce_bytes_per_step"] > 4 * 100e6      # both towers' fp32 gradients
+    assert c["grad_allreduce_calls_per_step"] >= 3 and c["allreduce_busy_ms_per_step"] > 0 and c["exposed_wait_ms_per_step"] >= 0
+    assert c["all_gather_calls_per_step"] == 4 and c["all_gather_bytes_per_step"] > 0
+    assert d["roofline"]["kernel"] and 0 <= d["roofline"]["frac"] < 1 and d["roofline"]["avg_launch_us"] > 0    # (8 pairs per rank: a tiny fraction)
+    assert "cpu_baseline" not in d                                                                               # (the CPU leg is N = 1 only)
+    full = json.load(open(detail))
+    assert full["value"] == d["value"] and len(full.get("roofline_other_kernels", [])) >= 5
+    assert "AccumulateGrad node's stream" not in r.stderr

@@ -75,6 +75,57 @@ def test_nt_epilogues(dev, M, N, K):
     np.testing.assert_allclose(y.cpu().numpy(), ((a.float() @ b.float().t()) * (hh.float() > 0)).cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
+def test_nt_gelu_epilogues_on_a_bert_ffn_shape_against_erf_gelu(dev):
+    """every NT GEMM with a bf16 output (BERT FFN and ViT MLP included) evaluates GELU / GELU' by the clamped polynomials of
+    csrc/common.h.  BERT-FFN shape (tokens x 3072 x 768) with pre-activations that SPAN [-8, 8] (one weight row per target value),
+    against torch's erf GELU in fp64: absolute error of a bf16 result = polynomial (<= 4.3e-4 relative for x > 0, <= 1.7e-4 absolute
+    for x < 0; exactly x / 0 beyond +-4) + bf16 rounding (2^-9 relative).  Non-finite pre-activations, documented behaviour: a NaN
+    pre-activation gives a NaN activation (x * t); GELU' clamps it away (fmed3 returns a finite operand), so a NaN in the SAVED h does
+    not propagate into the data gradient - the forward's own NaN output is what shows it; +-inf gives +inf / NaN (-inf * 0)."""
+    from mmgclip import linalg
+    from tests.conftest import measured
+    M, N, K = 1155, 3072, 768                      # 15 sequences of 77 tokens
+    a = torch.zeros(M, K, device=dev, dtype=torch.bfloat16)
+    a[:, 0] = 1.0                                   # pre[m, n] = b[n, 0] + bias[n]: exact control of the pre-activation
+    a[:, 1:] = _rand((M, K - 1), dev, 1.0, 11)
+    b = torch.zeros(N, K, device=dev, dtype=torch.bfloat16)
+    target = torch.linspace(-8.0, 8.0, N, device=dev)
+    b[:, 0] = target.to(torch.bfloat16)
+    b[:, 1:] = _rand((N, K - 1), dev, 0.02, 12)
+    bias = 0.01 * torch.randn(N, device=dev)
+    pre = a.double() @ b.double().t() + bias.double()
+    assert float(pre.min()) < -7.5 and float(pre.max()) > 7.5
+    h = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    y = linalg.gemm_nt(a, b, bias=bias, epi=linalg.EPI_GELU, aux_out=h)
+    ref = torch.nn.functional.gelu(pre)
+    err = (y.double() - ref).abs()
+    bar = 2.0 ** -8 * ref.abs() + 6e-4               # bf16 rounding of the result + the polynomial's bound
+    assert bool((err <= bar).all()), float((err - bar).max())
+    # data gradient through the saved bf16 pre-activation, bf16 output (the polynomial GELU') and fp32 output (the erf form)
+    dg = _rand((M, K), dev, 1.0, 13)
+    w = _rand((N, K), dev, 0.05, 14)
+    lin = dg.double() @ w.double().t()
+    x = h.double().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    want = lin * x.grad
+    y16 = linalg.gemm_nt(dg, w, epi=linalg.EPI_DGELU_ONLY, aux_in=h)
+    y32 = linalg.gemm_nt(dg, w, epi=linalg.EPI_DGELU_ONLY, aux_in=h, out_dtype=torch.float32)
+    e16 = float(((y16.double() - want).abs() / (2.0 ** -8 * want.abs() + 6e-4 * lin.abs() + 1e-3)).max())
+    e32 = float(((y32.double() - want).abs() / (1e-5 * want.abs() + 2e-5 * lin.abs() + 1e-4)).max())
+    measured("nt_gelu_bert_ffn_shape", gelu_max_abs_err=float(err.max()), gelu_max_err_over_bar=float((err / bar).max()),
+             dgelu_bf16_err_over_bar=e16, dgelu_fp32_err_over_bar=e32)
+    assert e16 <= 1.0 and e32 <= 1.0, (e16, e32)
+    # non-finite pre-activations (documented above)
+    b2 = b.clone()
+    b2[5, 0] = float("nan")
+    y_nan = linalg.gemm_nt(a[:256], b2, bias=bias, epi=linalg.EPI_GELU)
+    assert bool(torch.isnan(y_nan[:, 5]).all()) and bool(torch.isfinite(y_nan[:, :5]).all())
+    h_nan = h[:256].clone()
+    h_nan[:, 7] = float("nan")
+    g_nan = linalg.gemm_nt(dg[:256], w, epi=linalg.EPI_DGELU_ONLY, aux_in=h_nan)
+    assert bool(torch.isfinite(g_nan).all())          # GELU' clamps the NaN away: documented, not propagated
+
+
 def test_tn_integer_exact_asymmetric(dev):
     from mmgclip import linalg
     M, N1, N2 = 256, 128, 256

@@ -258,3 +258,55 @@ def test_two_stream_towers_give_the_same_step(dev, monkeypatch):
     for n, g0 in res["0"][1].items():
         g1 = res["1"][1][n]
         assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max()) + 1e-9, n
+
+
+_STREAM_SWITCH_SCRIPT = r"""
+import os, sys, warnings
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "mmg-clip_amd")):
+    sys.path.insert(0, p)
+os.environ["MMG_BERT_DROPOUT"] = "0"
+import torch
+from mmgclip.config import compose
+from mmgclip.dataset.synthetic import synthetic_batch
+from mmgclip.loss.loss_controller import create_loss
+from mmgclip.networks import bert
+from mmgclip.networks.mmgclip_model import MMGCLIP
+orig = bert.BertConfigLite.__init__
+def small(self, **kw):
+    kw.setdefault("num_hidden_layers", 2); kw.setdefault("vocab_size", 3000); orig(self, **kw)
+bert.BertConfigLite.__init__ = small
+cfg = compose(os.path.join(ROOT, "mmg-clip_amd", "configs"), "train_binary_class_clf",
+              ["networks=clip_convnexttiny_bert_pixels", "tokenizer=bert_clinical_seqlen=77", "networks/dropout=dropout0",
+               "networks.image_encoder.micro_batch=4", "networks.image_encoder.image_size=64"])
+model = MMGCLIP(cfg).train()
+crit = create_loss("CLIPLoss")()
+batch = synthetic_batch(8, S=77, image_size=64, vocab_size=3000, seed=4)
+kept = []
+with warnings.catch_warnings(record=True) as rec:
+    warnings.simplefilter("always")
+    for mode in (True, True, False, False, True):       # bench.py: timed steps on two streams, the roofline leg's on one, back again
+        model.text_stream_enabled = mode
+        model.zero_grad(set_to_none=True)
+        loss, _ = crit(**model(batch, materialize_logits=False))
+        loss.backward()
+        kept.append(loss)                                # the previous step's graph stays alive, as in bench.py (`loss = step()`)
+    torch.cuda.synchronize()
+bad = [str(w.message)[:120] for w in rec if "AccumulateGrad" in str(w.message)]
+print("STREAM_WARNINGS", len(bad), bad[:1])
+"""
+
+
+def test_no_accumulate_grad_stream_mismatch_when_the_text_tower_changes_stream(dev):
+    """torch warned "AccumulateGrad node's stream does not match the stream of the node that produced the incoming
+    gradient" in bench.py and in the 2-rank runs.  The node was the text tower's anchor leaf: created on the side stream by the timed
+    steps, kept alive by the loss of the last one, then fed from the main stream by the one-stream roofline steps.  The anchor is per
+    stream now (params.stream_anchor).  torch warns once per process, so the check runs in a fresh one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(CFG_DIR.rstrip("/")).rsplit("/mmg-clip_amd", 1)[0]
+    r = subprocess.run([sys.executable, "-c", _STREAM_SWITCH_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("STREAM_WARNINGS")][-1]
+    assert line.split()[1] == "0", line
+    assert "AccumulateGrad node's stream" not in r.stderr

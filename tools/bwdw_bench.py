@@ -50,14 +50,27 @@ def timed(fn, n=3):
     return s.elapsed_time(e) / n, out
 
 
+VARS = [v for v in os.environ.get("BWDW_VARS", "0,1,2").split(",") if v]      # launch-1 schedules (csrc/cnblock_bwdw.hip: VAR), same process
+
+
+def new_var(v):
+    os.environ["MMG_BWDW_VAR"] = v
+    return new()
+
+
 _, a = timed(old, 1)
-_, b = timed(new, 1)
 names = ("dd", "dW1", "db1", "dW2raw", "db2raw", "ln_dw", "ln_db")
-for n_, x, y in zip(names, a, b):
-    x, y = x.float(), y.float()
-    print(f"  {n_:7s} rel diff new vs old {float((x - y).norm() / x.norm()):.3e}   (|old| {float(x.norm()):.3e})", flush=True)
-del a, b
+for v in VARS:
+    _, b = timed(lambda: new_var(v), 1)
+    for n_, x, y in zip(names, a, b):
+        x, y = x.float(), y.float()
+        print(f"  VAR {v}: {n_:7s} rel diff new vs old {float((x - y).norm() / x.norm()):.3e}   (|old| {float(x.norm()):.3e})", flush=True)
+    del b
+del a
 for r in range(3):
     t_old, _ = timed(old)
-    t_new, _ = timed(new)
-    print(f"round {r}: old (mlp_bwd + 2 TN) {t_old:.3f} ms   new (bwdw, 2 launches) {t_new:.3f} ms   ratio {t_new / t_old:.3f}", flush=True)
+    line = f"round {r}: old (mlp_bwd + 2 TN) {t_old:.3f} ms"
+    for v in VARS:
+        t_new, _ = timed(lambda: new_var(v))
+        line += f" | VAR {v}: {t_new:.3f} ms ({t_new / t_old:.3f})"
+    print(line, flush=True)
