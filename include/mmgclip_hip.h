@@ -94,8 +94,9 @@ int mmg_clip_loss_reduce(const float* lse_a, const float* pos_a, const float* ls
  *     0 none | 1 GELU(erf) (aux_out, when given, receives the pre-activation) | 2 multiply by GELU'(aux_in)
  *     (aux_out, when given, receives GELU(aux_in): the activation rebuilt for the weight-gradient GEMM)
  *     3 ReLU (aux_out as 1)  | 4 ReLU' (gate by aux_in > 0; aux_out as 2)  | 5 multiply by GELU'(aux_in) only (ABI 4: for callers that
- *     kept GELU(h) from the forward; aux_out unused);  bf16 / e4m3 outputs of 1, 2 and 5 evaluate GELU / GELU' by the polynomials of
- *     csrc/common.h (2^-11 relative), fp32 outputs by the erf form (1.5e-7);
+ *     kept GELU(h) from the forward; aux_out unused) | 6 GELU(erf) whose aux_out receives GELU'(pre-activation) instead of the pre-activation
+ *     (ABI 5) | 7 multiply by aux_in (ABI 5: the data gradient of a layer whose forward ran 6 / kept GELU');
+ *     bf16 / e4m3 outputs of 1, 2, 5 and 6 evaluate GELU / GELU' by the polynomials of csrc/common.h (6e-4 relative), fp32 outputs by the erf form (1.5e-7);
  * then * colscale[N] (ConvNeXt layer scale), + residual[M,N] (bf16); C is bf16 (out_f32 = 0) or fp32.
  * K % 32 == 0, N % 8 == 0, leading dimensions multiples of 8.
  * Replaces nn.Linear forward / data-gradient in HF BertLayer (reference call site mmgclip/networks/encoder.py:156),
@@ -185,7 +186,12 @@ int mmg_dropout_bwd(const float* dy, const void* keep, float* dx, long long n, f
  * C % 32 == 0.  Replaces CNBlock.block[0] of torchvision ConvNeXt (mmgclip/networks/encoder.py:53). */
 int mmg_dwconv7_nhwc(const void* x, const float* w, const float* bias, const void* add, void* y, int n, int H, int W,
                      int C, int flip, mmg_stream_t stream);
-/* (ABI 4: mmg_dwconv7_nhwc_mfma - the same contract as Toeplitz-operand MFMAs, measured at parity in rounds 1 - 2 - was removed.) */
+/* The same contract on the matrix cores (ABI 5, csrc/dwconv7_mfma.hip): per channel and kernel row the 1-D convolution along x is a product with a
+ * banded Toeplitz matrix (v_mfma_f32_16x16x32_bf16, taps rounded to bf16, fp32 accumulation); the NHWC <-> channel-plane layout changes run on the
+ * LDS transposed reads.  With `add` the sum is rounded to bf16 twice (convolution, then + add).  (Rounds 1 - 2 had an earlier kernel of this name,
+ * at parity with the VALU one and removed in ABI 4.) */
+int mmg_dwconv7_nhwc_mfma(const void* x, const float* w, const float* bias, const void* add, void* y, int n, int H, int W,
+                          int C, int flip, mmg_stream_t stream);
 /* dw[49][C] += sum x(shifted) * dy ; dbias[C] += sum dy  (fp32, accumulated; dbias nullable) */
 int mmg_dwconv7_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int H, int W, int C,
                       mmg_stream_t stream);
@@ -204,10 +210,11 @@ int mmg_cnblock_pack_weights(const float* w1, const float* w2, const float* gamm
  * outputs for a backward that does not recompute them; xln (bf16 [M,C], the LayerNorm output = operand of that backward's
  * weight-gradient GEMM; optional, only next to hpre) saves it a LayerNorm pass; gact (bf16 [M,4C], GELU(hidden) as the second GEMM
  * consumed it; optional, only next to hpre) is the operand of that backward's dW2 GEMM, which lets its data-gradient GEMM run
- * epilogue 5 (GELU' only) instead of 2.  (ABI 2: xln added; ABI 4: gact added.) */
+ * epilogue 5 (GELU' only) instead of 2.  hpre_kind = 1 (ABI 5; needs hpre and gact): `hpre` receives GELU'(hidden) instead of the hidden -
+ * that data-gradient GEMM then runs epilogue 7, a multiply.  (ABI 2: xln added; ABI 4: gact added.) */
 int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
                         const float* b1, const float* b2, const float* gamma, const void* residual, void* y, void* hpre,
-                        void* xln, void* gact, float* mean, float* rstd, long long M, int C, mmg_stream_t stream);
+                        void* xln, void* gact, float* mean, float* rstd, int hpre_kind, long long M, int C, mmg_stream_t stream);
 
 /* Data path of the CNBlock MLP backward in one launch.  mmg_cnblock_mlp_bwd_supported(C): 1 (C in {96,128,192}) = the
  * hidden row h = LN(xd) W1^T + b1 is recomputed from the saved depthwise output, packed_bwd = pack(..., backward=1), hpre must

@@ -37,6 +37,8 @@ struct MlpFwd {
     long M; int ntiles;
     int nt;                                 // 4C-wide output larger than the Infinity Cache: store it past L2 (nontemporal)
     bf16_t* gact;                           // optional [M,4C] GELU(hidden) as the second GEMM consumed it (operand of that backward's dW2 GEMM)
+    int hkind;                              // what `hpre` receives: 0 = the pre-GELU hidden, 1 = GELU'(hidden) (round 4: that backward's data-gradient
+                                            // GEMM then runs epilogue 7, one multiply per element)
 };
 
 __device__ __forceinline__ void mlp_glds16(const void* gsrc, void* lds_wave_base) {
@@ -270,8 +272,13 @@ __global__ __launch_bounds__(RW ? RW * 64 : MlpCfg<C>::THREADS, RW ? RW / 4 : Ml
                     if (SAVE) {
                         const long row = row0 + 16 * mi;
                         if (row < p.M) {
-                            store16_stream(p.hpre + row * (4 * C) + n0,
-                                           make_uint4(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]), pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3])), p.nt);
+                            if (p.hkind)           // (uniform) GELU'(h) from the fp32 hidden: the exp-free polynomial the backward would have evaluated on bf16(h)
+                                store16_stream(p.hpre + row * (4 * C) + n0,
+                                               make_uint4(pack2bf(gelu_bf16_grad_poly(h0[0]), gelu_bf16_grad_poly(h0[1])), pack2bf(gelu_bf16_grad_poly(h0[2]), gelu_bf16_grad_poly(h0[3])),
+                                                          pack2bf(gelu_bf16_grad_poly(h1[0]), gelu_bf16_grad_poly(h1[1])), pack2bf(gelu_bf16_grad_poly(h1[2]), gelu_bf16_grad_poly(h1[3]))), p.nt);
+                            else
+                                store16_stream(p.hpre + row * (4 * C) + n0,
+                                               make_uint4(pack2bf(h0[0], h0[1]), pack2bf(h0[2], h0[3]), pack2bf(h1[0], h1[1]), pack2bf(h1[2], h1[3])), p.nt);
                         }
                     }
                     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -722,7 +729,7 @@ MMG_API int mmg_cnblock_pack_weights(const float* w1, const float* w2, const flo
 
 MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* ln_b, float eps, const void* packed,
                                 const float* b1, const float* b2, const float* gamma, const void* residual, void* y,
-                                void* hpre, void* xln, void* gact, float* mean, float* rstd, long long M, int C, hipStream_t stream) {
+                                void* hpre, void* xln, void* gact, float* mean, float* rstd, int hpre_kind, long long M, int C, hipStream_t stream) {
     MMG_CHECK_ARG(xd && ln_w && ln_b && packed && b1 && b2 && gamma && residual && y, "mmg_cnblock_mlp_fwd: null pointer");
     MMG_CHECK_ARG(mlp_supported(C), "mmg_cnblock_mlp_fwd: C=%d not in {96,128,192,256,384,512}", C);
     MMG_CHECK_ARG(M > 0 && M < (1LL << 36), "mmg_cnblock_mlp_fwd: bad M=%lld", M);
@@ -731,7 +738,8 @@ MMG_API int mmg_cnblock_mlp_fwd(const void* xd, const float* ln_w, const float* 
     MMG_CHECK_ARG(!xln || hpre, "mmg_cnblock_mlp_fwd: xln is saved next to hpre only");
     MMG_CHECK_ARG(!gact || hpre, "mmg_cnblock_mlp_fwd: gact is saved next to hpre only");
     MlpFwd p{(const bf16_t*)xd, ln_w, ln_b, eps, (const bf16_t*)packed, b1, b2, gamma, (const bf16_t*)residual, (bf16_t*)y,
-             (bf16_t*)hpre, (bf16_t*)xln, mean, rstd, (long)M, 0, 0, (bf16_t*)gact};
+             (bf16_t*)hpre, (bf16_t*)xln, mean, rstd, (long)M, 0, 0, (bf16_t*)gact, hpre_kind};
+    MMG_CHECK_ARG(hpre_kind == 0 || (hpre_kind == 1 && hpre && gact), "mmg_cnblock_mlp_fwd: hpre_kind=%d (1 = GELU' in place of the pre-activation) needs hpre and gact", hpre_kind);
     switch (C) {
         case 96: return launch_mlp_fwd<96>(p, stream);
         case 128: return launch_mlp_fwd<128>(p, stream);

@@ -128,19 +128,20 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
 // 22.8 against 18.4.  (Packed forms do not help: v_pk_fma_f32 = 3.9 slots per 2 elements, v_pk_fma_f16 = 1.65.)
 //     xc = clamp(x, -4, 4),  u = xc^2,  t = 0.5 + xc R(u) ~ Phi(x)  (R(16) * 4 = 0.5 exactly: t = 0 / 1 beyond the clamp)
 //     GELU(x) = x t,   GELU'(x) = t + xc phi(xc),  phi(xc) = 2^(-u log2(e) / 2) / sqrt(2 pi)
-// R: degree 7 in u, fitted by tools/fit_gelu.py.  Error of the fp32 evaluation over [-12, 12] against the exact function:
-// relative <= 4.3e-4 (2^-11) for x > 0, absolute <= 1.7e-4 for x < 0 (where |GELU| <= 0.17) - a bf16 result has a relative
+// R: degree 6 in u (degree 7 until round 3), fitted by tools/fit_gelu.py.  Error of the fp32 evaluation over [-12, 12] against the exact
+// function: relative <= 5.8e-4 for x > 0, absolute <= 2.4e-4 for x < 0 (where |GELU| <= 0.17) - a bf16 result has a relative
 // rounding error of up to 2^-8 = 3.9e-3; GELU' absolute <= 5.4e-4.  fp32 outputs keep gelu_f / gelu_grad_f (1.5e-7).
 __device__ __forceinline__ float gelu_bf16_t(float x, float& xc, float& u) {
     xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
     u = xc * xc;
-    float r = fmaf(-3.6202913771e-10f, u, 4.5281571812e-08f);
-    r = fmaf(r, u, -2.1615280625e-06f);
-    r = fmaf(r, u, 5.5186495382e-05f);
-    r = fmaf(r, u, -8.6428084215e-04f);
-    r = fmaf(r, u, 8.9540615968e-03f);
-    r = fmaf(r, u, -6.4865888188e-02f);
-    r = fmaf(r, u, 3.9801598429e-01f);      // (nudged so that the fp32 chain gives R(16) = 0.125 exactly)
+    // round 4: degree 6 in u (tools/fit_gelu.py, DEG = 6): one fma less per element in kernels that are bound by exactly these instructions;
+    // relative <= 5.8e-4 for x > 0, absolute <= 2.4e-4 for x < 0 (degree 7: 4.3e-4 / 1.7e-4) - a quarter of the bf16 rounding of the result
+    float r = fmaf(2.2038399460e-08f, u, -1.5565415077e-06f);
+    r = fmaf(r, u, 4.7013063952e-05f);
+    r = fmaf(r, u, -8.0343697344e-04f);
+    r = fmaf(r, u, 8.7106341480e-03f);
+    r = fmaf(r, u, -6.4399300920e-02f);
+    r = fmaf(r, u, 3.9770520692e-01f);      // (nudged so that the fp32 chain gives R(16) = 0.125 exactly)
     return fmaf(xc, r, 0.5f);
 }
 __device__ __forceinline__ float gelu_bf16(float x) {

@@ -25,7 +25,7 @@ void mmg_note_kernel(const char* fmt, ...) {
 MMG_API int mmg_set_kernel_notes(int on) { g_notes_on = on != 0; g_kernel[0] = 0; return 0; }
 MMG_API const char* mmg_last_kernel(void) { return g_kernel; }
 
-MMG_API int mmg_abi_version(void) { return 4; }
+MMG_API int mmg_abi_version(void) { return 5; }
 MMG_API const char* mmg_last_error(void) { return g_err; }
 MMG_API const char* mmg_target_arch(void) { return "gfx950"; }
 

@@ -27,7 +27,10 @@
 
 // EPI_DGELU_ONLY: the data gradient alone, C = (A B^T) * GELU'(aux_in) - for callers whose forward kept GELU(h) (round 3: the epilogue of
 // EPI_DGELU is VALU-bound and half of its arithmetic and stores rebuild that activation)
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RELU = 3, EPI_DRELU = 4, EPI_DGELU_ONLY = 5 };
+// Round 4: EPI_GELU_DAUX = GELU forward whose side output is GELU'(pre-activation) instead of the pre-activation, and
+// EPI_MUL_AUX = C = (A B^T) * aux_in - the data gradient of a layer whose forward kept GELU' (one multiply per element where EPI_DGELU_ONLY
+// evaluated a degree-7 polynomial: 19 000 of that tile's 53 600 cycles were this arithmetic, tools/nt_probe.py).
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RELU = 3, EPI_DRELU = 4, EPI_DGELU_ONLY = 5, EPI_GELU_DAUX = 6, EPI_MUL_AUX = 7 };
 
 struct GemmNT {
     const bf16_t* A; const bf16_t* B;
@@ -113,7 +116,26 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
     for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], alpha, bias[e]);
-    if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
+    if constexpr (EPI == EPI_GELU_DAUX) {
+        // GELU(v) out, GELU'(v) to aux_out (bf16 outputs: the two exp-free polynomials of common.h; fp32 / exact builds: the shared rcp / exp form)
+        float dv[8];
+#ifndef NT_GELU_EXACT
+        if (!g.out_f32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dv[e] = gelu_bf16_grad_poly(v[e]); v[e] = gelu_bf16(v[e]); }
+        } else
+#endif
+        {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float a, d; gelu_both(v[e], a, d); v[e] = a; dv[e] = d; }
+        }
+        if (g.aux_out)
+            store16(g.aux_out + (size_t)gr * g.ldao + gc, make_uint4(pack2bf(dv[0], dv[1]), pack2bf(dv[2], dv[3]), pack2bf(dv[4], dv[5]), pack2bf(dv[6], dv[7])), g.nt_store);
+    } else if constexpr (EPI == EPI_MUL_AUX) {
+        const unsigned hw[4] = {aux.x, aux.y, aux.z, aux.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] *= bf2f_lo(hw[e]); v[2 * e + 1] *= bf2f_hi(hw[e]); }
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
         if (g.aux_out) {
             uint4 o;
             o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
@@ -198,6 +220,8 @@ __device__ __forceinline__ void nt_epilogue_row_rt(const GemmNT& g, const float*
         case EPI_RELU: nt_epilogue_row<EPI_RELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
         case EPI_DRELU: nt_epilogue_row<EPI_DRELU>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
         case EPI_DGELU_ONLY: nt_epilogue_row<EPI_DGELU_ONLY>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
+        case EPI_GELU_DAUX: nt_epilogue_row<EPI_GELU_DAUX>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
+        case EPI_MUL_AUX: nt_epilogue_row<EPI_MUL_AUX>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
         default: nt_epilogue_row<EPI_NONE>(g, crow, gr, gc, bias, cs, res, aux, alpha); break;
     }
 }
@@ -404,7 +428,7 @@ __global__ __launch_bounds__(WAVES_M * 128, BN > 128 ? 1 : ((NST == 3 && BK == 3
     // accumulators go through LDS, so their latency overlaps the staging instead of being paid pass by pass.
     constexpr bool PREFETCH = PASSES <= 8;                // (wider tiles: 16 passes of prefetch would spill)
     uint4 res_v[PREFETCH ? PASSES : 1], aux_v[PREFETCH ? PASSES : 1];
-    const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DGELU_ONLY || g.epi == EPI_DRELU);
+    const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DGELU_ONLY || g.epi == EPI_DRELU || g.epi == EPI_MUL_AUX);
     const float alpha = g.alpha_dev ? g.alpha * *g.alpha_dev : g.alpha;
 #pragma unroll
     for (int p = 0; p < (PREFETCH ? PASSES : 0); ++p) {
@@ -427,7 +451,7 @@ __global__ __launch_bounds__(WAVES_M * 128, BN > 128 ? 1 : ((NST == 3 && BK == 3
     auto epilogue = [&](auto epi_tag) {
         constexpr int TAG = decltype(epi_tag)::value;
         constexpr int EPI = TAG < 0 ? -1 : (TAG & 15), RES = TAG < 0 ? -1 : (TAG >> 4);
-        constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DGELU_ONLY || EPI == EPI_DRELU);
+        constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DGELU_ONLY || EPI == EPI_DRELU || EPI == EPI_MUL_AUX);
 #ifdef NT_EPI_READS_LATE
         constexpr bool AHEAD = false;
 #else
@@ -516,6 +540,8 @@ __global__ __launch_bounds__(WAVES_M * 128, BN > 128 ? 1 : ((NST == 3 && BK == 3
         case EPI_RELU + 16: epilogue(std::integral_constant<int, EPI_RELU + 16>{}); break;
         case EPI_DRELU: epilogue(std::integral_constant<int, EPI_DRELU>{}); break;
         case EPI_DGELU_ONLY: epilogue(std::integral_constant<int, EPI_DGELU_ONLY>{}); break;
+        case EPI_GELU_DAUX: epilogue(std::integral_constant<int, EPI_GELU_DAUX>{}); break;
+        case EPI_MUL_AUX: epilogue(std::integral_constant<int, EPI_MUL_AUX>{}); break;
         default: epilogue(std::integral_constant<int, -1>{}); break;
     }
 #ifdef NT_PROBE
@@ -552,8 +578,8 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     MMG_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0,
                   "mmg_gemm_nt_bf16: leading dimensions must cover the row and be multiples of 8 (lda=%d ldb=%d ldc=%d)",
                   lda, ldb, ldc);
-    MMG_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_DGELU_ONLY, "mmg_gemm_nt_bf16: unknown epilogue %d", epi);
-    MMG_CHECK_ARG(!(epi == EPI_DGELU || epi == EPI_DGELU_ONLY || epi == EPI_DRELU) || (aux_in && ldai >= N && ldai % 8 == 0),
+    MMG_CHECK_ARG(epi >= EPI_NONE && epi <= EPI_MUL_AUX, "mmg_gemm_nt_bf16: unknown epilogue %d", epi);
+    MMG_CHECK_ARG(!(epi == EPI_DGELU || epi == EPI_DGELU_ONLY || epi == EPI_DRELU || epi == EPI_MUL_AUX) || (aux_in && ldai >= N && ldai % 8 == 0),
                   "mmg_gemm_nt_bf16: activation-gradient epilogue needs aux_in");
     MMG_CHECK_ARG(!residual || (ldr >= N && ldr % 8 == 0), "mmg_gemm_nt_bf16: bad ldr=%d", ldr);
     MMG_CHECK_ARG(!aux_out || (ldao >= N && ldao % 8 == 0), "mmg_gemm_nt_bf16: bad ldao=%d", ldao);
@@ -589,7 +615,12 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     const bool fills = !fill_rule || f256 >= 0.8 * f128;
     // (round 3, tools/nt_deep_ab.sh: the same tile on 32-column stages, three or four of them - more K tiles in flight at short K - was 2-3 %
     // SLOWER on the K = 384 / 768 fat-epilogue shapes, 2883 / 2915 against 2827 us: the main loop is not waiting for its operands.  Removed.)
+    // round 4: N = 192 / 384 (ConvNeXt stage-3 d LN-out = dh W1: 1 M x 384 x 1536, 13.6 ms of a C2 step on 128 x 128 tiles at 0.33 of the MFMA peak)
+    // take a 256 x 192 tile - the 256 x 256 kernel's 8 waves with 64 x 96 wave tiles (0.42 fragment reads per MFMA against 0.5)
+    const int use_192 = getenv("MMG_GEMM_192") ? atoi(getenv("MMG_GEMM_192")) : 384;      // (read per call: same-process A/B, tools/nt_192_ab.py)
+    const double f192 = fill((long)cdiv(M, 256) * cdiv(N, 192));
     if (use_256 && k64 && N % 256 == 0 && M >= 4096 && K >= use_256 && fills) launch_nt<256, 256, 64, 4, 2>(g, stream);
+    else if (use_192 && k64 && N % 192 == 0 && M >= 4096 && K >= use_192 && (!fill_rule || f192 >= 0.8 * f128)) launch_nt<256, 192, 64, 4, 2>(g, stream);
     else if (use_3wg && !n96 && K % 32 == 0 && K < k3_max) launch_nt<128, 128, 32, 2, 3>(g, stream);
     else if (use_big && k64 && !n96 && M >= 4096 && K >= kbig_min) launch_nt<256, 128, 64, 4, 3>(g, stream);
     else if (n96) { if (k64) launch_nt<128, 96, 64, 2, 2>(g, stream); else launch_nt<128, 96, 32, 2, 2>(g, stream); }

@@ -13,7 +13,7 @@ _PKG_ROOT = os.path.dirname(_HERE)                      # mmg-clip_amd/
 _REPO_ROOT = os.path.dirname(_PKG_ROOT)
 LIB_PATH = os.environ.get("MMGCLIP_HIP_LIB", os.path.join(_PKG_ROOT, "csrc", "libmmgclip_hip.so"))
 HEADER_PATH = os.path.join(_REPO_ROOT, "include", "mmgclip_hip.h")
-ABI_VERSION = 4      # 2: mmg_cnblock_mlp_fwd gained the optional xln output; the dropout entry points; 3: kernel-name notes; 4: cnblock_mlp_fwd gact, NT epilogue 5
+ABI_VERSION = 5      # 5: mmg_dwconv7_nhwc_mfma (round 4); 2: mmg_cnblock_mlp_fwd gained the optional xln output; the dropout entry points; 3: kernel-name notes; 4: cnblock_mlp_fwd gact, NT epilogue 5
 
 _CTYPES = {
     "int": ctypes.c_int,

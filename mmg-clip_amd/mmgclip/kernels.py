@@ -143,9 +143,25 @@ def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0)
          float(eps), float(wd), int(step), float(grad_scale), stream())
 
 
+def dwconv_mfma_pays(n, H, W, C, flip):
+    """Where the matrix-core kernel beat the VALU one in the same-process A/B at the benchmark's batch (tools/dwm_scale.py, profiles/
+    r04_dwconv_mfma_scale.txt, n = 256): few channel slabs (its persistent grid deals 32 workgroups per XCD group over C / 32 slabs: at C = 384 /
+    768 a quarter of them idle); the data gradient (+ residual operand) only at C = 96.  The rule reads the MAP size and the width only, never the
+    image count: a tower must take the same kernel whatever micro-batch it is run in (taps are rounded to bf16 here, kept fp32 there)."""
+    return H * W >= 96 * 96 and (C <= 96 if flip else C <= 192)
+
+
 def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None):
     y = out if out is not None else torch.empty(n * H * W, C, device=x.device, dtype=BF16)
     px = n * H * W * C
+    # MMG_DWCONV_MFMA (read per call: A/B runs): 1 = the Toeplitz-operand matrix-core kernel (csrc/dwconv7_mfma.hip, taps rounded to bf16),
+    # 0 = the fp32 VALU kernels (csrc/dwconv7.hip), unset / auto = by shape (dwconv_mfma_pays)
+    mode = os.environ.get("MMG_DWCONV_MFMA", "auto")
+    if mode == "1" or (mode == "auto" and dwconv_mfma_pays(n, H, W, C, flip)):
+        PROFILE.timed("dwconv7_mfma_kernel", 98.0 * px, (6 if add is not None else 4) * px,
+                      lambda: call("mmg_dwconv7_nhwc_mfma", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()),
+                      f"n={n} {H}x{W} C={C}" + (" +add" if add is not None else ""))
+        return y
     fam = "dwconv7_rows2_kernel" if os.environ.get("MMG_DWCONV_ROWS2", "1") != "0" else "dwconv7_kernel"
     PROFILE.timed(fam, 98.0 * px, (6 if add is not None else 4) * px,
                   lambda: call("mmg_dwconv7_nhwc", ptr(x), ptr(w49), ptr(bias), ptr(add), ptr(y), n, H, W, C, 1 if flip else 0, stream()),
@@ -176,9 +192,10 @@ def cnblock_pack(w1, w2, gamma=None, backward=False):
     return out
 
 
-def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_hpre=False, want_stats=False, want_xln=False, want_gact=False):
+def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_hpre=False, want_stats=False, want_xln=False, want_gact=False,
+                    hpre_kind=0):
     """-> y, hpre, mean, rstd (and, with want_xln, the LayerNorm output as a fifth value; with want_gact, GELU(hidden) - the activation as
-    the second GEMM consumed it, bf16 [M,4C] - as the last value)."""
+    the second GEMM consumed it, bf16 [M,4C] - as the last value).  hpre_kind = 1 (with want_gact): `hpre` holds GELU'(hidden)."""
     M, C = xd.shape
     y = torch.empty_like(xd)
     hpre = torch.empty(M, 4 * C, device=xd.device, dtype=BF16) if want_hpre else None
@@ -190,7 +207,8 @@ def cnblock_mlp_fwd(xd, ln_w, ln_b, eps, packed, b1, b2, gamma, residual, want_h
     PROFILE.timed("cnblock_mlp_fwd_kernel", 16.0 * M * C * C,
                   (6 + (8 if want_hpre else 0) + (2 if xln is not None else 0) + (8 if gact is not None else 0)) * M * C + 16 * C * C,
                   lambda: call("mmg_cnblock_mlp_fwd", ptr(xd), ptr(ln_w), ptr(ln_b), float(eps), ptr(packed), ptr(b1), ptr(b2),
-                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(xln), ptr(gact), ptr(mean), ptr(rstd), M, C, stream()),
+                               ptr(gamma), ptr(residual), ptr(y), ptr(hpre), ptr(xln), ptr(gact), ptr(mean), ptr(rstd),
+                               int(hpre_kind) if gact is not None else 0, M, C, stream()),
                   f"M={M} C={C}" + (" +hpre" if want_hpre else "") + (" +xln" if xln is not None else "") + (" +gact" if gact is not None else ""))
     out = (y, hpre, mean, rstd) + ((xln,) if want_xln else ())
     return out + ((gact,) if want_gact else ())

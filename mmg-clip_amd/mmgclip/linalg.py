@@ -3,7 +3,7 @@ import torch
 
 from ._hip import call, ptr, stream
 
-EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_DGELU_ONLY = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_DGELU_ONLY, EPI_GELU_DAUX, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def _ld(t):
@@ -67,7 +67,7 @@ from .profile import PROFILE  # noqa: E402  (bench.py reads linalg.PROFILE)
 
 _gemm_nt_raw = gemm_nt
 _gemm_tn_raw = gemm_tn_acc
-_EPI_NAMES = {EPI_NONE: "none", EPI_GELU: "gelu", EPI_DGELU: "dgelu", EPI_RELU: "relu", EPI_DRELU: "drelu", EPI_DGELU_ONLY: "dgelu_only"}
+_EPI_NAMES = {EPI_NONE: "none", EPI_GELU: "gelu", EPI_DGELU: "dgelu", EPI_RELU: "relu", EPI_DRELU: "drelu", EPI_DGELU_ONLY: "dgelu_only", EPI_GELU_DAUX: "gelu+dgelu_aux", EPI_MUL_AUX: "mul_aux"}
 
 
 def _nt_label(M, N, K, kw):

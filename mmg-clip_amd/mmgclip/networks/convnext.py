@@ -102,6 +102,8 @@ class ConvNextTower(nn.Module):
         # below 15 % of the device memory (C2: 33.8 GB on; ConvNeXt-B without checkpointing: 131 GB, off).  MMG_SAVE_GELU=0 / 1 force it.
         self.save_gelu_mode = os.environ.get("MMG_SAVE_GELU", "auto")
         self.save_gelu = self.save_gelu_mode == "1"
+        # with GELU(h) kept, keep GELU'(h) instead of h as the second 4C-wide tensor (round 4; MMG_SAVE_DGELU=0: h, and the polynomial in the backward)
+        self.save_dgelu = os.environ.get("MMG_SAVE_DGELU", "1") != "0"
         self.checkpoint = checkpoint        # recompute each micro-batch's forward in the backward (north-star config C5)
         # fp8 (config C5): the two pointwise GEMMs of every block with C % 128 == 0 and C >= fp8_min_channels run their FORWARD
         # on e4m3 operands (LayerNorm / GELU outputs cast unscaled, weights with a per-tensor power-of-two scale); the backward
@@ -221,9 +223,12 @@ class ConvNextTower(nn.Module):
                     keep_ln = keep and self.save_ln and key + ".mlpb2" not in wc
                     # ... and (save_gelu) GELU(hidden) as the second GEMM consumed it: that backward's data-gradient GEMM then applies GELU' only
                     keep_g = keep and self.save_gelu and key + ".mlpb2" not in wc
+                    # round 4: with GELU(hidden) kept, the second saved 4C-wide tensor is GELU'(hidden) instead of the hidden itself (same bytes): the
+                    # backward's data-gradient GEMM then multiplies by it (NT epilogue 7) instead of evaluating the polynomial per element
                     outs = K.cnblock_mlp_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, wc[key + ".mlp"],
                                              blk.block[3].bias.data, blk.block[5].bias.data, blk.layer_scale.data.reshape(C), x,
-                                             want_hpre=keep, want_stats=keep, want_xln=keep_ln, want_gact=keep_g)
+                                             want_hpre=keep, want_stats=keep, want_xln=keep_ln, want_gact=keep_g,
+                                             hpre_kind=1 if (keep_g and self.save_dgelu) else 0)
                     xn, hpre, mean, rstd = outs[:4]
                     ln = outs[4] if keep_ln else None
                     gact = outs[-1] if keep_g else None
@@ -240,7 +245,8 @@ class ConvNextTower(nn.Module):
                                        residual=x, alpha_dev=wc[key + ".s2"][1:])
                 else:
                     ln, mean, rstd = K.layernorm_fwd(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=save)
-                    g = L.gemm_nt(ln, wc[key + ".w1"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre)
+                    g = L.gemm_nt(ln, wc[key + ".w1"], bias=blk.block[3].bias.data, aux_out=hpre,
+                                  epi=L.EPI_GELU_DAUX if (save and self.save_gelu and self.save_dgelu) else L.EPI_GELU)   # (hpre = GELU'(h) then)
                     xn = L.gemm_nt(g, wc[key + ".w2"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
                                    residual=x)
                 if save:                         # (an e4m3 LayerNorm output / activation is not what the bf16 backward reads: those are recomputed)
@@ -310,7 +316,8 @@ class ConvNextTower(nn.Module):
                 else:
                     if g_saved is not None:                # the forward kept GELU(h): GELU' only (half the epilogue's arithmetic and stores)
                         g = g_saved
-                        dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU_ONLY, aux_in=hpre)
+                        # ... and (save_dgelu) GELU'(h) in place of h: one multiply per element
+                        dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_MUL_AUX if self.save_dgelu else L.EPI_DGELU_ONLY, aux_in=hpre)
                     else:
                         g = torch.empty_like(hpre)         # GELU(hpre), rebuilt by the same epilogue that applies GELU'
                         dh = L.gemm_nt(dx, wc[key + ".w2gt"], epi=L.EPI_DGELU, aux_in=hpre, aux_out=g)

@@ -8,7 +8,7 @@ from mmgclip import _hip
 def test_library_exists_and_loads():
     assert os.path.isfile(_hip.LIB_PATH), "run __graft_entry__.build() first"
     lib = _hip.load()
-    assert lib.mmg_abi_version() == 4
+    assert lib.mmg_abi_version() == 5
     assert lib.mmg_target_arch() == b"gfx950"
 
 

@@ -68,6 +68,18 @@ def test_nt_epilogues(dev, M, N, K):
     y5 = linalg.gemm_nt(a, b, epi=linalg.EPI_DGELU_ONLY, aux_in=hh, out_dtype=torch.float32)
     assert torch.equal(y5, y)
     assert torch.equal(linalg.gemm_nt(a, b, epi=linalg.EPI_DGELU_ONLY, aux_in=hh), y2)
+    # epilogue 6 (round 4): GELU forward whose side output is GELU'(pre-activation); epilogue 7: multiply by that saved tensor - together the
+    # data gradient of epilogue 5 up to the bf16 rounding of the saved derivative (computed from the fp32 pre-activation here, from bf16(h) there)
+    dsave = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    y6 = linalg.gemm_nt(a, b, bias=bias, epi=linalg.EPI_GELU_DAUX, aux_out=dsave)
+    assert torch.equal(y6, linalg.gemm_nt(a, b, bias=bias, epi=linalg.EPI_GELU))
+    xp = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(xp).sum().backward()
+    np.testing.assert_allclose(dsave.float().cpu().numpy(), xp.grad.cpu().numpy(), rtol=2 ** -8, atol=6e-4)
+    y7 = linalg.gemm_nt(a, b, epi=linalg.EPI_MUL_AUX, aux_in=dsave, out_dtype=torch.float32)
+    np.testing.assert_allclose(y7.cpu().numpy(), ((a.float() @ b.float().t()) * dsave.float()).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    y7b = linalg.gemm_nt(a, b, epi=linalg.EPI_MUL_AUX, aux_in=dsave)
+    np.testing.assert_allclose(y7b.float().cpu().numpy(), ((a.float() @ b.float().t()) * xp.grad).cpu().numpy(), rtol=1e-2, atol=1e-2)
     # ReLU pair
     y = linalg.gemm_nt(a, b, bias=bias, epi=linalg.EPI_RELU, out_dtype=torch.float32)
     np.testing.assert_allclose(y.cpu().numpy(), torch.relu(pre).cpu().numpy(), rtol=1e-4, atol=1e-3)
@@ -78,7 +90,7 @@ def test_nt_epilogues(dev, M, N, K):
 def test_nt_gelu_epilogues_on_a_bert_ffn_shape_against_erf_gelu(dev):
     """every NT GEMM with a bf16 output (BERT FFN and ViT MLP included) evaluates GELU / GELU' by the clamped polynomials of
     csrc/common.h.  BERT-FFN shape (tokens x 3072 x 768) with pre-activations that SPAN [-8, 8] (one weight row per target value),
-    against torch's erf GELU in fp64: absolute error of a bf16 result = polynomial (<= 4.3e-4 relative for x > 0, <= 1.7e-4 absolute
+    against torch's erf GELU in fp64: absolute error of a bf16 result = polynomial (<= 5.8e-4 relative for x > 0, <= 2.4e-4 absolute
     for x < 0; exactly x / 0 beyond +-4) + bf16 rounding (2^-9 relative).  Non-finite pre-activations, documented behaviour: a NaN
     pre-activation gives a NaN activation (x * t); GELU' clamps it away (fmed3 returns a finite operand), so a NaN in the SAVED h does
     not propagate into the data gradient - the forward's own NaN output is what shows it; +-inf gives +inf / NaN (-inf * 0)."""
@@ -212,9 +224,9 @@ def test_nt_fp8_epilogues(dev, M, N, K):
     h_ref = q_e4m3(torch.nn.functional.gelu(pre_ref).float())
     h = h8.cpu().view(torch.float8_e4m3fn).float()
     # an e4m3 step is 6-12 % of the value: a result on a rounding boundary may land on either neighbour, never further.  The
-    # polynomial GELU (relative error <= 4.3e-4, common.h) moves results within 2 * 4.3e-4 / 0.06 ~ 1.4 % of a boundary across it.
+    # polynomial GELU (relative error <= 5.8e-4, common.h; degree 6 since round 4) moves results within 2 * 5.8e-4 / 0.06 ~ 1.9 % of a boundary across it.
     mism = (h != h_ref)
-    assert float(mism.float().mean()) < 1.5e-2, float(mism.float().mean())
+    assert float(mism.float().mean()) < 2.5e-2, float(mism.float().mean())
     assert bool(((h - h_ref).abs() <= torch.maximum(0.126 * torch.maximum(h.abs(), h_ref.abs()), torch.tensor(2.0 ** -9))).all())
     out = L.gemm_nt_fp8(a8.to(dev), b8.to(dev), bias=bias.to(dev), colscale=cs.to(dev), residual=res.to(dev), alpha=0.25,
                         alpha_dev=alpha_dev)

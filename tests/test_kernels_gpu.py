@@ -112,6 +112,7 @@ def test_adamw_matches_torch(dev):
 @pytest.mark.parametrize("n,H,W,C", [(2, 32, 32, 96), (1, 56, 56, 96), (2, 14, 14, 384), (3, 7, 7, 768), (1, 64, 40, 192), (2, 37, 50, 64)])
 def test_dwconv7(dev, n, H, W, C, monkeypatch):
     from mmgclip import kernels as K
+    monkeypatch.setenv("MMG_DWCONV_MFMA", "0")      # the fp32-tap VALU kernels (the matrix-core kernel has its own test below)
     x = _r((n, H, W, C), dev, 16).to(BF)
     w = _r((C, 1, 7, 7), dev, 17, 0.1)
     b = _r((C,), dev, 18)
@@ -132,10 +133,12 @@ def test_dwconv7(dev, n, H, W, C, monkeypatch):
     assert torch.equal(K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C), y)
     assert torch.equal(K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True), dx)
     monkeypatch.undo()
+    monkeypatch.setenv("MMG_DWCONV_MFMA", "0")
     monkeypatch.setenv("MMG_DWCONV_TH", "16")     # 16-row tiles (two passes over one staged tile): the same sums in the same order
     assert torch.equal(K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C), y)
     assert torch.equal(K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True), dx)
     monkeypatch.undo()
+    monkeypatch.setenv("MMG_DWCONV_MFMA", "0")
     for rows2, th in (("1", "8"), ("1", "16"), ("0", "8")):   # two dy rows per lane on 8- and 16-row tiles (defaults by size) / one
         monkeypatch.setenv("MMG_DWCONV_ROWS2", rows2)
         monkeypatch.setenv("MMG_DWG_TH", th)
@@ -143,6 +146,39 @@ def test_dwconv7(dev, n, H, W, C, monkeypatch):
         K.dwconv7_wgrad(x.reshape(-1, C), dy.reshape(-1, C), dw, db, n, H, W, C)
         _close(dw, wr.grad.reshape(C, 49).t(), 2e-3, 2e-3 * (n * H * W) ** 0.5)
         _close(db, br.grad, 2e-3, 2e-3 * (n * H * W) ** 0.5)
+
+
+@pytest.mark.parametrize("n,H,W,C", [(2, 32, 32, 96), (1, 56, 56, 96), (2, 14, 14, 384), (3, 7, 7, 768), (1, 64, 40, 192), (2, 37, 50, 64), (5, 48, 80, 128)])
+def test_dwconv7_matrix_core_kernel(dev, n, H, W, C, monkeypatch):
+    """csrc/dwconv7_mfma.hip (round 4): forward and data gradient of the depthwise 7x7 convolution as Toeplitz-operand MFMAs, against fp32
+    torch AND against the VALU kernels.  The taps are rounded to bf16 here (fp32 there): against torch with bf16-rounded weights the only
+    errors left are the fp32 accumulation order and the output rounding; maps that are not multiples of the 16 x 16 tile, several items
+    per workgroup (persistent loop, double-buffered halo tiles) and the residual-gradient operand are covered."""
+    from mmgclip import kernels as K
+    from tests.conftest import measured
+    x = _r((n, H, W, C), dev, 16).to(BF)
+    w = _r((C, 1, 7, 7), dev, 17, 0.1)
+    b = _r((C,), dev, 18)
+    w49 = w.reshape(C, 49).t().contiguous()
+    monkeypatch.setenv("MMG_DWCONV_MFMA", "1")
+    y = K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C)
+    wq = w.to(BF).float()                                       # what the matrix cores multiply by
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wq, b, padding=3, groups=C).permute(0, 2, 3, 1)
+    _close(y.reshape(n, H, W, C), ref, 5e-3, 1e-2)             # bf16 output rounding only (2^-9 relative)
+    ref32 = F.conv2d(x.float().permute(0, 3, 1, 2), w, b, padding=3, groups=C).permute(0, 2, 3, 1)
+    _close(y.reshape(n, H, W, C), ref32, 1e-2, 2e-2)            # the bar of the VALU kernel's test
+    dy = _r((n, H, W, C), dev, 19).to(BF)
+    res = _r((n * H * W, C), dev, 20).to(BF)
+    dx = K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True)
+    dref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wq, None, padding=3, groups=C).permute(0, 2, 3, 1)
+    _close(dx.reshape(n, H, W, C), dref + res.float().reshape(n, H, W, C), 1e-2, 3e-2)
+    monkeypatch.setenv("MMG_DWCONV_MFMA", "0")
+    yv = K.dwconv7(x.reshape(-1, C), w49, b, n, H, W, C)
+    dxv = K.dwconv7(dy.reshape(-1, C), w49, None, n, H, W, C, add=res, flip=True)
+    _close(y, yv, 1e-2, 2e-2)
+    _close(dx, dxv, 1e-2, 3e-2)
+    measured("dwconv7_mfma_vs_valu", n=n, H=H, W=W, C=C, fwd_max_abs=float((y.float() - yv.float()).abs().max()),
+             fwd_vs_bf16_tap_torch=float((y.reshape(n, H, W, C).float() - ref).abs().max()))
 
 
 def _attn_ref(qkv, mask, B, S, heads):
@@ -465,7 +501,7 @@ def test_cnblock_fp8_forward_one_block(dev, M, C):
 
 def test_polynomial_gelu_over_every_bf16_input(dev):
     """csrc/common.h gelu_bf16 / gelu_bf16_grad (the forms used wherever the result is rounded to bf16): EVERY finite bf16 input,
-    against erf-GELU in fp64.  Stated bars: relative 2^-11 for x > 0, absolute 1.7e-4 for x < 0 (GELU), absolute 5.4e-4 (GELU');
+    against erf-GELU in fp64.  Stated bars (round 4: the degree-6 polynomial): relative 5.8e-4 for x > 0, absolute 2.4e-4 for x < 0 (GELU), absolute 5.4e-4 (GELU');
     on top of each, the rounding of the bf16 result itself (relative 2^-8)."""
     import math
     from mmgclip import kernels as K
@@ -479,8 +515,8 @@ def test_polynomial_gelu_over_every_bf16_input(dev):
     ref = 0.5 * xd * (1 + torch.erf(xd / math.sqrt(2)))
     err = (y - ref).abs()
     tiny = 1e-37                                            # (subnormal results flush)
-    assert (err[xd > 0] <= (2 ** -8 + 2 ** -11) * ref[xd > 0].abs() + tiny).all()
-    assert (err[xd < 0] <= 2 ** -8 * ref[xd < 0].abs() + 1.7e-4).all()
+    assert (err[xd > 0] <= (2 ** -8 + 5.8e-4) * ref[xd > 0].abs() + tiny).all()
+    assert (err[xd < 0] <= 2 ** -8 * ref[xd < 0].abs() + 2.4e-4).all()
     big = xd.abs() > 8                                      # beyond the clamp: identity / (to 1e-6 |x|) zero
     assert (y[big & (xd > 0)] == xd[big & (xd > 0)]).all() and (y[big & (xd < 0)].abs() <= 1e-6 * xd[big & (xd < 0)].abs()).all()
     # derivative: mmg_act_grad_bf16 applied to a gradient of ones

@@ -24,7 +24,13 @@ for n, H, C in [(16, 256, 96), (16, 128, 192), (16, 64, 384), (16, 32, 768)]:
     out = torch.empty_like(x)
     dw, db = torch.zeros(49, C, device=dev), torch.zeros(C, device=dev)
     fl = 2.0 * 49 * n * H * H * C
-    t1 = timeit(lambda: K.dwconv7(x, w, b, n, H, H, C, out=out))
-    t2 = timeit(lambda: K.dwconv7(dy, w, None, n, H, H, C, add=x, flip=True, out=out))
+    for rnd in range(2):          # MFMA (csrc/dwconv7_mfma.hip) against VALU (csrc/dwconv7.hip), interleaved in one process
+        line = f"DW n={n} H={H} C={C} round {rnd}:"
+        for mode in ("0", "1"):
+            os.environ["MMG_DWCONV_MFMA"] = mode
+            t1 = timeit(lambda: K.dwconv7(x, w, b, n, H, H, C, out=out))
+            t2 = timeit(lambda: K.dwconv7(dy, w, None, n, H, H, C, add=x, flip=True, out=out))
+            line += f"  {'mfma' if mode == '1' else 'valu'}: fwd {t1:7.1f} us {fl/t1/1e6:6.1f} TF/s, bwd-data {t2:7.1f} us {fl/t2/1e6:6.1f} TF/s |"
+        print(line, flush=True)
     t3 = timeit(lambda: K.dwconv7_wgrad(x, dy, dw, db, n, H, H, C))
-    print(f"DW n={n} H={H} C={C}: fwd {t1:7.1f} us {fl/t1/1e6:6.1f} TF/s | bwd-data {t2:7.1f} us {fl/t2/1e6:6.1f} TF/s | wgrad {t3:7.1f} us {fl/t3/1e6:6.1f} TF/s", flush=True)
+    print(f"DW n={n} H={H} C={C}: wgrad {t3:7.1f} us {fl/t3/1e6:6.1f} TF/s", flush=True)

@@ -9,7 +9,7 @@ that beyond the clamp t is exactly 0 / 1.  Error weight: the GELU error x^2 |dR|
 import numpy as np
 from scipy.special import erf
 
-C_CLAMP, DEG = 4.0, 7
+C_CLAMP, DEG = 4.0, 6      # round 4: degree 6 (one fma less; 5.8e-4 / 2.3e-4 instead of 4.3e-4 / 1.7e-4, still a quarter of a bf16 ulp)
 
 
 def gelu(x):
