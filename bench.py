@@ -157,6 +157,17 @@ def build(args, comm):
     return cfg, model, criterion, arenas
 
 
+def _fp8_dtype(model):
+    """What the --fp8 run computed in: the ConvNeXt blocks from `fp8_min_channels` up run their pointwise GEMMs on e4m3 (forward) and - round 4,
+    unless MMG_FP8_BWD=0 - e5m2 x e4m3 (both data-gradient and both weight-gradient GEMMs) operands with fp32 accumulation; everything else bf16."""
+    t = getattr(model, "image_encoder", None)
+    t = getattr(t, "tower", t)
+    c = getattr(t, "fp8_min_channels", 512)
+    if getattr(t, "fp8_bwd", False):
+        return f"fp8 (e4m3 forward + e5m2/e4m3 backward GEMMs in the C >= {c} ConvNeXt blocks; bf16 elsewhere)"
+    return f"bf16 (fp8 e4m3 forward GEMMs in the C >= {c} ConvNeXt blocks)"
+
+
 def _host_cores():
     try:
         n = len(os.sched_getaffinity(0))
@@ -403,7 +414,7 @@ def main():
         "metric": "image-text pairs/sec (global batch)", "value": round(value, 2), "unit": "image-text pairs/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (fp8 e4m3 forward GEMMs in the C >= 512 ConvNeXt blocks)" if args.fp8 and args.variant != "vit_b16" else "bf16",
+        "dtype": _fp8_dtype(model) if args.fp8 and args.variant != "vit_b16" else "bf16",
         "data": "synthetic",
         "config": {"workload": (f"reference-faithful: train_binary_class_clf, pre-extracted 768-d image features + frozen BERT-base S={args.seq_len} "
                                 f"(forward only), LinearProjection 768->512 x2 trained, CLIPLoss, AdamW") if args.variant == "faithful" else

@@ -267,12 +267,30 @@ int mmg_cluster_mean_cols_bwd(const float* dout, int ldo, int n, int N, const lo
  * bf16 MFMA rate, half the operand bytes).  Backward stays bf16 (saved pre-activations and bf16 weight copies). */
 
 /* C[M,N] = epilogue( alpha * (alpha_dev ? *alpha_dev : 1) * A[M,K] B[N,K]^T + bias ): A, B e4m3 bytes row-major (K contiguous,
- * lda / ldb in bytes, multiples of 16), fp32 accumulate.  Epilogue as mmg_gemm_nt_bf16 with epi in {0 none, 1 GELU, 3 ReLU};
+ * lda / ldb in bytes, multiples of 16), fp32 accumulate.  Epilogue as mmg_gemm_nt_bf16 with epi in {0 none, 1 GELU, 3 ReLU, 6 GELU + GELU' side output};
  * out_kind: 0 bf16 | 1 fp32 | 2 e4m3 bytes (saturating at +-448; ldc in elements of that type).  K % 128 == 0, N % 8 == 0.
  * alpha_dev: device scalar, e.g. scales[1] of mmg_quantize_e4m3_f32 (so weight scales never visit the host). */
 int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                     const float* bias, const float* colscale, const void* residual, int ldr, void* aux_out, int ldao,
                     int epi, int out_kind, float alpha, const float* alpha_dev, mmg_stream_t stream);
+
+/* ---- fp8 backward of the ConvNeXt blocks (ABI 5; BASELINE config C5 "ConvNeXt-base fp8 MFMA path"; the reference itself has no fp8) ---------- */
+
+/* src bf16 [n] -> dst OCP e5m2 bytes [n] with the per-tensor power-of-two scale 2^floor(log2(16384 / max|src|)) computed on the device
+ * (amax fp32 [1] is scratch); scales fp32 [2] = (scale, 1 / scale).  n % 8 == 0.  The gradient entering a CNBlock backward
+ * (torchvision CNBlock behind mmgclip/networks/encoder.py:53). */
+int mmg_quantize_e5m2_bf16(const void* src, long long n, float* amax, void* dst, float* scales, mmg_stream_t stream);
+/* C[M,N] = epilogue( alpha * alpha_dev * alpha_dev2 * A[M,K] B[N,K]^T ): A = e5m2 (a_e5m2 != 0) or e4m3 bytes, B e4m3 bytes, fp32 accumulate on the
+ * K = 128 MFMA; epi 0 none | 5 multiply by GELU'(aux_in) | 7 multiply by aux_in (aux_in bf16 [M,N]); C bf16 / fp32 / e5m2 bytes (out_kind 0 / 1 / 3).
+ * The two data-gradient GEMMs of a CNBlock (dh = (dy (gamma W2)) * GELU'(h) handed on in 8 bits, d LN-out = dh W1).  K % 128 == 0. */
+int mmg_gemm_nt_fp8_bwd(const void* A, int lda, int a_e5m2, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                        const void* aux_in, int ldai, int epi, int out_kind, float alpha, const float* alpha_dev,
+                        const float* alpha_dev2, mmg_stream_t stream);
+/* C[N1,N2] (fp32) += alpha * alpha_dev * A[M,N1]^T B[M,N2]: A e5m2 (a_e5m2 != 0) or e4m3 bytes, B e4m3 bytes, both row-major with the reduction index
+ * slow (transposed 8-bit fragment reads, ds_read_b64_tr_b8); colsum_a [N1] (optional) += alpha * alpha_dev * column sums of A.  N1, N2, lda, ldb
+ * multiples of 16.  The two weight-gradient GEMMs of a CNBlock on the 8-bit operands its forward / data-gradient GEMMs already hold. */
+int mmg_gemm_tn_fp8(const void* A, int lda, int a_e5m2, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+                    float alpha, const float* alpha_dev, float* colsum_a, mmg_stream_t stream);
 
 /* amax[0] = max(amax[0], max |src[i]|) (caller zeroes amax);  then  dst = e4m3(src * scale) with the power-of-two
  * scale = 2^floor(log2(448 / amax)) (1 when amax is null / 0), scales[0] = scale, scales[1] = 1 / scale.  n % 4 == 0. */

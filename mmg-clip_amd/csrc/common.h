@@ -66,6 +66,15 @@ __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float 
     return (unsigned)v;
 }
 
+// four floats -> four OCP e5m2 bytes (v_cvt_pk_bf8_f32, round-to-nearest-even), saturating at +-57344
+__device__ __forceinline__ unsigned pack4_e5m2(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -57344.f, 57344.f); b = __builtin_amdgcn_fmed3f(b, -57344.f, 57344.f);
+    c = __builtin_amdgcn_fmed3f(c, -57344.f, 57344.f); d = __builtin_amdgcn_fmed3f(d, -57344.f, 57344.f);
+    int v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

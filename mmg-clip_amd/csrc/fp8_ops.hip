@@ -48,3 +48,50 @@ MMG_API int mmg_quantize_e4m3_f32(const float* src, long long n, const float* am
     MMG_LAUNCH_CHECK("mmg_quantize_e4m3_f32");
     return 0;
 }
+
+// ---- gradients: bf16 -> OCP e5m2 with a per-tensor power-of-two scale (fp8 backward of config C5, round 4) -------------------------------------------
+// amax[0] = max(amax[0], max |src|) over bf16 elements (16 bytes per lane)
+__global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint4* __restrict__ src, size_t n8, unsigned* __restrict__ amax) {
+    unsigned m = 0;                                           // |x| as bf16 bits in the high half: orders like the value
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 v = src[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned lo = (w[e] << 16) & 0x7fff0000u, hi = w[e] & 0x7fff0000u;
+            m = lo > m ? lo : m; m = hi > m ? hi : m;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, m);          // (float bits; NaN / inf inputs give a NaN / inf amax: scale 1 below)
+}
+
+// scale = 2^floor(log2(16384 / amax)): the largest |src * scale| lands in [8192, 16384] - a factor 3.5 below e5m2's 57344, the headroom the
+// data-gradient GEMM's output (written with the SAME scale) gets; 1 when amax is 0 or not finite.  dst = e5m2(src * scale), scales = (scale, 1 / scale).
+__global__ __launch_bounds__(256) void quantize_e5m2_kernel(const uint4* __restrict__ src, size_t n8, const float* __restrict__ amax,
+                                                            uint2* __restrict__ dst, float* __restrict__ scales) {
+    const float a = *amax;
+    float scale = 1.f;
+    if (a > 0.f && a < 3.0e38f) scale = exp2f(floorf(log2f(16384.f / a)));
+    if (a * scale > 16384.f) scale *= 0.5f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && scales) { scales[0] = scale; scales[1] = 1.f / scale; }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 v = src[i];
+        dst[i] = make_uint2(pack4_e5m2(bf2f_lo(v.x) * scale, bf2f_hi(v.x) * scale, bf2f_lo(v.y) * scale, bf2f_hi(v.y) * scale),
+                            pack4_e5m2(bf2f_lo(v.z) * scale, bf2f_hi(v.z) * scale, bf2f_lo(v.w) * scale, bf2f_hi(v.w) * scale));
+    }
+}
+
+// src bf16 [n] (n % 8 == 0, 16-byte aligned) -> dst e5m2 bytes [n], scales fp32 [2] = (scale, 1 / scale); amax fp32 [1] is scratch (zeroed here).
+MMG_API int mmg_quantize_e5m2_bf16(const void* src, long long n, float* amax, void* dst, float* scales, hipStream_t stream) {
+    MMG_CHECK_ARG(src && dst && amax && scales && n > 0 && n % 8 == 0, "mmg_quantize_e5m2_bf16: n=%lld must be a positive multiple of 8", n);
+    const size_t n8 = (size_t)n / 8;
+    int blocks = cdiv((long)n8, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (hipMemsetAsync(amax, 0, 4, stream) != hipSuccess) { mmg_set_error("mmg_quantize_e5m2_bf16: memset failed"); return 2; }
+    hipLaunchKernelGGL(absmax_bf16_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, n8, reinterpret_cast<unsigned*>(amax));
+    hipLaunchKernelGGL(quantize_e5m2_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, n8, amax, (uint2*)dst, scales);
+    MMG_LAUNCH_CHECK("mmg_quantize_e5m2_bf16");
+    return 0;
+}

@@ -46,8 +46,9 @@ struct GemmNT {
     int tiles_m, tiles_n;
     int nt_store;             // stream the outputs past L2 (they are not re-read before they would be evicted anyway)
     // fp8 path (mmg_gemm_nt_fp8): A / B hold OCP e4m3 bytes; K, lda, ldb are passed here in 2-byte units
-    int out_fp8;              // C receives e4m3 bytes (saturating), ldc in bytes
+    int out_fp8;              // C receives 8-bit floats (saturating), ldc in bytes: 1 = e4m3, 2 = e5m2
     const float* alpha_dev;   // optional device scalar multiplied into alpha (1 / weight scale, produced on the device)
+    const float* alpha_dev2;  // a second one (1 / gradient scale of the fp8 backward)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -198,7 +199,10 @@ __device__ __forceinline__ void nt_epilogue_row(const GemmNT& g, const float* cr
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f_lo(rw[e]); v[2 * e + 1] += bf2f_hi(rw[e]); }
     }
-    if (g.out_fp8) {
+    if (g.out_fp8 == 2) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(g.C) + (size_t)gr * g.ldc + gc) =
+            make_uint2(pack4_e5m2(v[0], v[1], v[2], v[3]), pack4_e5m2(v[4], v[5], v[6], v[7]));
+    } else if (g.out_fp8) {
         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(g.C) + (size_t)gr * g.ldc + gc) =
             make_uint2(pack4_e4m3(v[0], v[1], v[2], v[3]), pack4_e4m3(v[4], v[5], v[6], v[7]));
     } else if (g.out_f32) {
@@ -274,7 +278,7 @@ MMG_API int mmg_debug_nt_probe(unsigned long long* out8, int reset) {
 
 template <int BM, int BN, int BK, int WAVES_M, int NST, int F8 = 0>
 __global__ __launch_bounds__(WAVES_M * 128, BN > 128 ? 1 : ((NST == 3 && BK == 32) ? 3 : 2)) void gemm_nt_kernel(const GemmNT g) {
-    static_assert(!F8 || BK == 64, "fp8 operands: one 128-byte K tile = one 16x16x128 MFMA step");
+    static_assert(!F8 || BK == 64, "fp8 operands: one 128-byte K tile = one 16x16x128 MFMA step");      // F8: 1 = A e4m3, 2 = A e5m2 (gradients); B e4m3
     constexpr int THREADS = WAVES_M * 128;
     constexpr int MI = 4, NI = BN / 32;                  // 16x16 fragments per wave (wave tile 64 x BN/2)
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(WAVES_M * 128, BN > 128 ? 1 : ((NST == 3 && BK == 3
                         for (int i = 0; i < MI; ++i)
 #pragma unroll
                             for (int j = 0; j < NJ; ++j)
-                                acc[i][j0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[i][j0 + j], 0, 0, 0, 0, 0, 0);
+                                acc[i][j0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[i][j0 + j], 0, F8 == 2 ? 1 : 0, 0, 0, 0, 0);   // (B = weights e4m3; A e4m3 / e5m2)
                     }
                 } else {
 #pragma unroll
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(WAVES_M * 128, BN > 128 ? 1 : ((NST == 3 && BK == 3
     constexpr bool PREFETCH = PASSES <= 8;                // (wider tiles: 16 passes of prefetch would spill)
     uint4 res_v[PREFETCH ? PASSES : 1], aux_v[PREFETCH ? PASSES : 1];
     const bool want_aux = (g.epi == EPI_DGELU || g.epi == EPI_DGELU_ONLY || g.epi == EPI_DRELU || g.epi == EPI_MUL_AUX);
-    const float alpha = g.alpha_dev ? g.alpha * *g.alpha_dev : g.alpha;
+    const float alpha = (g.alpha_dev ? g.alpha * *g.alpha_dev : g.alpha) * (g.alpha_dev2 ? *g.alpha_dev2 : 1.0f);
 #pragma unroll
     for (int p = 0; p < (PREFETCH ? PASSES : 0); ++p) {
         const int rl = tr + (p % QP) * RPP;
@@ -587,7 +591,7 @@ MMG_API int mmg_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, voi
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.bias = bias; g.colscale = colscale;
     g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = (const bf16_t*)aux_in; g.ldai = ldai;
-    g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.out_fp8 = 0; g.alpha_dev = nullptr;
+    g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.out_fp8 = 0; g.alpha_dev = nullptr; g.alpha_dev2 = nullptr;
     static const int force_bk = getenv("MMG_GEMM_BK") ? atoi(getenv("MMG_GEMM_BK")) : 0;   // tuning knobs
     static const int use_big = getenv("MMG_GEMM_V2") ? atoi(getenv("MMG_GEMM_V2")) : 1;
     // outputs larger than the 256 MiB Infinity Cache cannot be re-read from cache anyway: stream them past L2
@@ -642,20 +646,50 @@ MMG_API int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void
     MMG_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && ldc % 8 == 0,
                   "mmg_gemm_nt_fp8: leading dimensions must cover the row; lda/ldb multiples of 16 bytes, ldc of 8 "
                   "(lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
-    MMG_CHECK_ARG(epi == EPI_NONE || epi == EPI_GELU || epi == EPI_RELU, "mmg_gemm_nt_fp8: epilogue %d not available", epi);
+    MMG_CHECK_ARG(epi == EPI_NONE || epi == EPI_GELU || epi == EPI_RELU || epi == EPI_GELU_DAUX, "mmg_gemm_nt_fp8: epilogue %d not available", epi);
     MMG_CHECK_ARG(!residual || (ldr >= N && ldr % 8 == 0), "mmg_gemm_nt_fp8: bad ldr=%d", ldr);
     MMG_CHECK_ARG(!aux_out || (ldao >= N && ldao % 8 == 0), "mmg_gemm_nt_fp8: bad ldao=%d", ldao);
     GemmNT g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
     g.C = C; g.ldc = ldc; g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 2; g.bias = bias; g.colscale = colscale;
     g.residual = (const bf16_t*)residual; g.ldr = ldr; g.aux_in = nullptr; g.ldai = 0;
-    g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.alpha_dev = alpha_dev;
+    g.aux_out = (bf16_t*)aux_out; g.ldao = ldao; g.epi = epi; g.alpha = alpha; g.alpha_dev = alpha_dev; g.alpha_dev2 = nullptr;
     g.nt_store = (size_t)M * N * (out_kind == 1 ? 4 : out_kind == 2 ? 1 : 2) >= ((size_t)256 << 20);
     static const int tile = getenv("MMG_FP8_TILE") ? atoi(getenv("MMG_FP8_TILE")) : 0;   // tuning: 1 = 256x128, 2 = 128x128
     if (tile == 0 && N % 256 == 0 && M >= 4096) launch_nt<256, 256, 64, 4, 2, 1>(g, stream);
     else if (tile != 2 && M >= 4096) launch_nt<256, 128, 64, 4, 3, 1>(g, stream);
     else launch_nt<128, 128, 64, 2, 2, 1>(g, stream);
     MMG_LAUNCH_CHECK("mmg_gemm_nt_fp8");
+    return 0;
+}
+
+// Data-gradient GEMMs of the fp8 backward (round 4): A = a gradient in OCP e5m2 (a_e5m2 != 0) or e4m3 bytes, B = e4m3 weights, fp32 accumulate on the
+// K = 128 MFMA; epilogue 0 (none), 5 (x GELU'(aux_in)) or 7 (x aux_in); C bf16 / fp32 / e5m2 (out_kind 0 / 1 / 3: the gradient handed on in 8 bits,
+// written once).  alpha_dev / alpha_dev2: device scalars multiplied into alpha (1 / weight scale, 1 / gradient scale).
+MMG_API int mmg_gemm_nt_fp8_bwd(const void* A, int lda, int a_e5m2, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                const void* aux_in, int ldai, int epi, int out_kind, float alpha, const float* alpha_dev,
+                                const float* alpha_dev2, hipStream_t stream) {
+    MMG_CHECK_ARG(A && B && C, "mmg_gemm_nt_fp8_bwd: null operand");
+    MMG_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 128 == 0 && N % 8 == 0, "mmg_gemm_nt_fp8_bwd: M=%d N=%d K=%d (K a multiple of 128, N of 8)", M, N, K);
+    MMG_CHECK_ARG(out_kind == 0 || out_kind == 1 || out_kind == 3, "mmg_gemm_nt_fp8_bwd: out_kind=%d (0 bf16, 1 fp32, 3 e5m2)", out_kind);
+    MMG_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && ldc % 8 == 0,
+                  "mmg_gemm_nt_fp8_bwd: leading dimensions must cover the row; lda/ldb multiples of 16 bytes, ldc of 8 (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    MMG_CHECK_ARG(epi == EPI_NONE || epi == EPI_DGELU_ONLY || epi == EPI_MUL_AUX, "mmg_gemm_nt_fp8_bwd: epilogue %d not available", epi);
+    MMG_CHECK_ARG(epi == EPI_NONE || (aux_in && ldai >= N && ldai % 8 == 0), "mmg_gemm_nt_fp8_bwd: the activation-gradient epilogues need aux_in");
+    GemmNT g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K / 2; g.lda = lda / 2; g.ldb = ldb / 2;
+    g.C = C; g.ldc = ldc; g.out_f32 = out_kind == 1; g.out_fp8 = out_kind == 3 ? 2 : 0; g.bias = nullptr; g.colscale = nullptr;
+    g.residual = nullptr; g.ldr = 0; g.aux_in = (const bf16_t*)aux_in; g.ldai = ldai; g.aux_out = nullptr; g.ldao = 0;
+    g.epi = epi; g.alpha = alpha; g.alpha_dev = alpha_dev; g.alpha_dev2 = alpha_dev2;
+    g.nt_store = (size_t)M * N * (out_kind == 1 ? 4 : out_kind == 3 ? 1 : 2) >= ((size_t)256 << 20);
+    if (a_e5m2) {
+        if (N % 256 == 0 && M >= 4096) launch_nt<256, 256, 64, 4, 2, 2>(g, stream);
+        else launch_nt<128, 128, 64, 2, 2, 2>(g, stream);
+    } else {
+        if (N % 256 == 0 && M >= 4096) launch_nt<256, 256, 64, 4, 2, 1>(g, stream);
+        else launch_nt<128, 128, 64, 2, 2, 1>(g, stream);
+    }
+    MMG_LAUNCH_CHECK("mmg_gemm_nt_fp8_bwd");
     return 0;
 }
 

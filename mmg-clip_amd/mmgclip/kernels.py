@@ -69,6 +69,17 @@ def layernorm_fwd_fp8(x, gamma, beta, eps, want_stats=True):
     return y, mean, rstd
 
 
+def quantize_e5m2(x):
+    """bf16 tensor (numel % 8 == 0) -> (e5m2 bytes uint8 of x.shape, scales fp32 [2] = (scale, 1/scale)), per-tensor power-of-two scale from
+    the tensor's own absmax, computed and consumed on the device (the gradient operand of the fp8 backward, csrc/fp8_ops.hip)."""
+    assert x.dtype == BF16 and x.is_contiguous()
+    q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    scales = torch.empty(2, device=x.device, dtype=torch.float32)
+    amax = torch.empty(1, device=x.device, dtype=torch.float32)
+    call("mmg_quantize_e5m2_bf16", ptr(x), x.numel(), ptr(amax), ptr(q), ptr(scales), stream())
+    return q, scales
+
+
 def quantize_e4m3(w):
     """fp32 tensor -> (e4m3 bytes uint8 of w.shape, scales fp32 [2] = (scale, 1/scale)) with the per-tensor power-of-two
     scale 2^floor(log2(448 / max|w|)); amax and scale stay on the device."""

@@ -109,7 +109,13 @@ class ConvNextTower(nn.Module):
         # on e4m3 operands (LayerNorm / GELU outputs cast unscaled, weights with a per-tensor power-of-two scale); the backward
         # stays bf16 on the saved pre-activation.  Default 512: the stages whose blocks are GEMM pairs anyway.
         self.fp8 = bool(fp8)
-        self.fp8_min_channels = int(os.environ.get("MMG_FP8_MIN_C", "512")) if fp8_min_channels is None else int(fp8_min_channels)
+        # round 4: the same blocks' BACKWARD in 8 bits too (MMG_FP8_BWD=0: the bf16 backward of rounds 1 - 3): the incoming gradient is cast to e5m2
+        # with a per-tensor power-of-two scale, both data-gradient GEMMs run on e5m2 x e4m3 operands (dh handed on in e5m2, written once), both
+        # weight-gradient GEMMs on the 8-bit operands the forward / data path already hold (csrc/gemm_tn_fp8.hip)
+        self.fp8_bwd = os.environ.get("MMG_FP8_BWD", "1") != "0"
+        # (round 4, with the 8-bit backward: 256 - same-box A/B of `bench.py --variant base --fp8 --checkpoint`: 925 ms/step from C = 256, 939 from 512,
+        #  936 from 128: at C = 256 the GEMM pair's 4C-wide tensors are 8-bit in both directions now; rounds 1 - 3, forward only: no difference, 512)
+        self.fp8_min_channels = int(os.environ.get("MMG_FP8_MIN_C", "256" if self.fp8_bwd else "512")) if fp8_min_channels is None else int(fp8_min_channels)
         self.dims, self.depths = CONFIGS[variant]["dims"], CONFIGS[variant]["depths"]
         self.model = _TorchvisionLayout(variant, in_chans)
         self.model_output_dimension = self.dims[-1]
@@ -160,6 +166,10 @@ class ConvNextTower(nn.Module):
                 if self._fp8_block(C):                                                       # e4m3 bytes + (scale, 1/scale)
                     wc[key + ".w1f8"], wc[key + ".s1"] = K.quantize_e4m3(blk.block[3].weight.data)
                     wc[key + ".w2f8"], wc[key + ".s2"] = K.quantize_e4m3(blk.block[5].weight.data)
+                    if self.fp8_bwd:         # the data-gradient GEMMs' weights: (gamma W2)^T [4C, C] and W1^T [C, 4C], e4m3 + (scale, 1/scale)
+                        wc[key + ".w2gt8"], wc[key + ".s2gt"] = K.quantize_e4m3(
+                            (blk.block[5].weight.data * blk.layer_scale.data.reshape(C, 1)).t().contiguous())
+                        wc[key + ".w1t8"], wc[key + ".s1t"] = K.quantize_e4m3(blk.block[3].weight.data.t().contiguous())
                 elif self.fused_mlp and K.cnblock_supported(C):                              # packed LDS images
                     wc[key + ".mlp"] = K.cnblock_pack(blk.block[3].weight.data, blk.block[5].weight.data)
                     mode = K.cnblock_bwd_mode(C)     # 1: hidden row recomputed; 2: reads the forward's saved pre-activation
@@ -216,7 +226,9 @@ class ConvNextTower(nn.Module):
                 d = K.dwconv7(x, wc[key + ".w49"], blk.block[0].bias.data, n, h, w_, C)
                 # LN + Linear + GELU + Linear + layer scale + residual in one launch (C = 512, ConvNeXt-B stage 3: only when nothing
                 # is saved for a backward - with the 4C-wide pre-activation store it is no faster than the GEMM pair)
-                if key + ".mlp" in wc and (C <= 384 or not save):
+                # MMG_MLP_FUSED_SAVE_MAXC (A/B knob, round 4): widest block whose SAVING forward stays on the fused kernel - at C = 384 that kernel
+                # stores three 4C- / C-wide streams beside its output and the GEMM pair (256 x 256 and 256 x 192 tiles) is within reach of it
+                if key + ".mlp" in wc and (C <= int(os.environ.get("MMG_MLP_FUSED_SAVE_MAXC", "384")) or not save):
                     keep = save and key + ".mlpb" not in wc      # the fused backward recomputes the hidden row
                     # a GEMM-pair backward (C = 384 by default) also gets the LayerNorm output from the forward's registers: one
                     # [M,C] store instead of a LayerNorm pass over d in the backward
@@ -239,7 +251,10 @@ class ConvNextTower(nn.Module):
                 hpre = torch.empty(x.shape[0], 4 * C, device=x.device, dtype=torch.bfloat16) if save else None
                 if key + ".w1f8" in wc:      # e4m3 operands, fp32 accumulate; the saved pre-activation stays bf16
                     ln, mean, rstd = K.layernorm_fwd_fp8(d, blk.block[2].weight.data, blk.block[2].bias.data, LN_EPS, want_stats=save)
-                    g = L.gemm_nt_fp8(ln, wc[key + ".w1f8"], bias=blk.block[3].bias.data, epi=L.EPI_GELU, aux_out=hpre,
+                    # (8-bit backward: the side output is GELU'(h) - its data-gradient GEMM multiplies by it - and the e4m3 LayerNorm output /
+                    #  activation are kept: they ARE the weight-gradient GEMMs' operands)
+                    g = L.gemm_nt_fp8(ln, wc[key + ".w1f8"], bias=blk.block[3].bias.data, aux_out=hpre,
+                                      epi=L.EPI_GELU_DAUX if (save and key + ".w2gt8" in wc) else L.EPI_GELU,
                                       out_kind=L.OUT_E4M3, alpha_dev=wc[key + ".s1"][1:])
                     xn = L.gemm_nt_fp8(g, wc[key + ".w2f8"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
                                        residual=x, alpha_dev=wc[key + ".s2"][1:])
@@ -250,8 +265,11 @@ class ConvNextTower(nn.Module):
                     xn = L.gemm_nt(g, wc[key + ".w2"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
                                    residual=x)
                 if save:                         # (an e4m3 LayerNorm output / activation is not what the bf16 backward reads: those are recomputed)
-                    saved[key] = (x, d, mean, rstd, hpre, ln if (self.save_ln and ln.dtype == torch.bfloat16) else None,
-                                  g if (self.save_gelu and g.dtype == torch.bfloat16) else None)
+                    if key + ".w2gt8" in wc:
+                        saved[key] = (x, d, mean, rstd, hpre, ln, g)         # (uint8 tensors: the 8-bit backward below)
+                    else:
+                        saved[key] = (x, d, mean, rstd, hpre, ln if (self.save_ln and ln.dtype == torch.bfloat16) else None,
+                                      g if (self.save_gelu and g.dtype == torch.bfloat16) else None)
                 del ln, g
                 x = xn
             if si < 3:
@@ -313,6 +331,16 @@ class ConvNextTower(nn.Module):
                     del g
                     L.gemm_tn_acc(dh, ln, gname(blk.block[3], "weight"), colsum=gname(blk.block[3], "bias"))
                     del ln, dh
+                elif g_saved is not None and g_saved.dtype == torch.uint8:
+                    # 8-bit backward (config C5): hpre holds GELU'(h) (bf16), ln_saved / g_saved the e4m3 operands of the forward GEMMs
+                    dy8, sdy = K.quantize_e5m2(dx)
+                    dh8 = L.gemm_nt_fp8_bwd(dy8, wc[key + ".w2gt8"], aux_in=hpre, epi=L.EPI_MUL_AUX, out_kind=L.OUT_E5M2,
+                                            alpha_dev=wc[key + ".s2gt"][1:])               # e5m2 at dy's scale: (acc / s_w) * GELU'
+                    L.gemm_tn_fp8_acc(dy8, g_saved, tmp[key + ".dw2raw"], alpha_dev=sdy[1:])
+                    L.colsum_acc(dx, tmp[key + ".db2raw"])                                  # (the bias gradient from the bf16 gradient itself)
+                    L.gemm_tn_fp8_acc(dh8, ln_saved, gname(blk.block[3], "weight"), alpha_dev=sdy[1:], colsum=gname(blk.block[3], "bias"))
+                    dln = L.gemm_nt_fp8_bwd(dh8, wc[key + ".w1t8"], alpha_dev=wc[key + ".s1t"][1:], alpha_dev2=sdy[1:])
+                    del dh8, dy8
                 else:
                     if g_saved is not None:                # the forward kept GELU(h): GELU' only (half the epilogue's arithmetic and stores)
                         g = g_saved

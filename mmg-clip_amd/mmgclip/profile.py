@@ -121,7 +121,8 @@ class KernelProfile:
                       "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4),
                       "arithmetic_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1)})
             return r
-        fp8 = "fp8" in stats.get("family", kernel) or (kernel.startswith("gemm_nt_kernel<") and kernel.endswith(", 1>"))
+        fp8 = "fp8" in stats.get("family", kernel) or "tn8" in stats.get("family", kernel) or \
+            (kernel.startswith("gemm_nt_kernel<") and kernel.endswith((", 1>", ", 2>")))
         r = one(stats, fp8)
         r["kernel"] = kernel
         r["family"] = stats.get("family", kernel)

@@ -41,11 +41,12 @@ def q_e4m3_weight(w):
     return q_e4m3(w * scale) / scale
 
 
-def convnext_forward(sd, images, depths=(3, 3, 9, 3), scale16=True, prefix="features.", fp8_min_channels=None):
+def convnext_forward(sd, images, depths=(3, 3, 9, 3), scale16=True, prefix="features.", fp8_min_channels=None, fp8_backward=False):
     """torchvision ConvNeXt `features` + `avgpool` from a state dict (fp32).  images [n,Cin,H,W]; returns [n,C,1,1].
     fp8_min_channels: blocks with C % 128 == 0 and C >= that value run their two Linear layers on e4m3 operands (LayerNorm and
     GELU outputs rounded to e4m3 unscaled, weights per-tensor scaled), fp32 accumulation - BASELINE config C5's forward; the
-    rounding is a straight-through identity for autograd, as the bf16 backward of the build treats it."""
+    rounding is a straight-through identity for autograd, as the bf16 backward of the build treats it; fp8_backward=True: those blocks' backward in
+    8 bits as well (Fp8BlockMLP below: e5m2 gradients, the build's round-4 default)."""
     x = images
     if scale16:
         x = 65535.0 * x
@@ -67,6 +68,11 @@ def convnext_forward(sd, images, depths=(3, 3, 9, 3), scale16=True, prefix="feat
             y = F.conv2d(x, g(k + "block.0.weight"), g(k + "block.0.bias"), padding=3, groups=C)
             y = y.permute(0, 2, 3, 1)
             y = F.layer_norm(y, (C,), g(k + "block.2.weight"), g(k + "block.2.bias"), 1e-6)
+            if fp8_backward and fp8_min_channels is not None and C % 128 == 0 and C >= fp8_min_channels:
+                y = Fp8BlockMLP.apply(y, g(k + "block.3.weight"), g(k + "block.3.bias"), g(k + "block.5.weight"), g(k + "block.5.bias"),
+                                      g(k + "layer_scale").reshape(C))
+                x = x + y.permute(0, 3, 1, 2)
+                continue
             if fp8_min_channels is not None and C % 128 == 0 and C >= fp8_min_channels:
                 ste = lambda t, q: t + (q - t).detach()                    # noqa: E731  value of q, gradient of t
                 w1, w2 = g(k + "block.3.weight"), g(k + "block.5.weight")
@@ -202,3 +208,57 @@ def resnet50_forward(sd, images, train_bn=True, prefix="", storage_bf16=False):
             idn = bn(conv(x, k + "downsample.0.weight", stride=s), k + "downsample.1", relu=False) if bi == 0 else x
             x = bn(y, k + "bn3", res=idn)
     return F.adaptive_avg_pool2d(x, 1).flatten(1)
+
+
+# ---- the 8-bit backward of config C5's blocks (round 4) -------------------------------------------------------------------------------------------
+def q_e5m2(t):
+    """Round to OCP e5m2 (round-to-nearest-even, saturating at +-57344) and back to fp32."""
+    return t.clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(torch.float32)
+
+
+def e5m2_scale(t):
+    """Per-tensor power-of-two gradient scale as csrc/fp8_ops.hip (quantize_e5m2_kernel): 2^floor(log2(16384 / max|t|)), 1 for an all-zero tensor."""
+    amax = float(t.detach().abs().max())
+    scale = 1.0
+    if 0.0 < amax < 3.0e38:
+        scale = 2.0 ** math.floor(math.log2(16384.0 / amax))
+        if amax * scale > 16384.0:
+            scale *= 0.5
+    return scale
+
+
+class Fp8BlockMLP(torch.autograd.Function):
+    """gamma * ( GELU( q(ln) q(W1)^T + b1 ) -> q -> q(W2)^T + b2 ) of a CNBlock (LayerNorm output `ln` [.., C]) with the arithmetic of the
+    build's fp8 path in BOTH directions (mmgclip/networks/convnext.py, the `.w2gt8` branch):
+      forward   e4m3 operands, fp32 accumulation (as convnext_forward's straight-through form);
+      backward  dy8 = e5m2(dy s) with s = e5m2_scale(dy);  dh8 = e5m2((dy8 q(gamma W2)) GELU'(h)) at the SAME scale;
+                d ln = (dh8 / s) q(W1);  dW2 = gamma (dy8^T g8) / s,  db2 = gamma colsum(dy) (from dy itself),  dW1 = (dh8^T ln8) / s,
+                db1 = colsum(dh8) / s,  d gamma = sum over rows of dy * (the forward's MLP output)."""
+
+    @staticmethod
+    def forward(ctx, ln, w1, b1, w2, b2, gamma):
+        ln8 = q_e4m3(ln)
+        h = F.linear(ln8, q_e4m3_weight(w1), b1)
+        g8 = q_e4m3(F.gelu(h))
+        y = F.linear(g8, q_e4m3_weight(w2), b2)
+        ctx.save_for_backward(ln8, h, g8, y, w1, w2, gamma)
+        return gamma * y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ln8, h, g8, y, w1, w2, gamma = ctx.saved_tensors
+        C = dy.shape[-1]
+        dyf, lnf, hf, gf = dy.reshape(-1, C), ln8.reshape(-1, C), h.reshape(-1, 4 * C), g8.reshape(-1, 4 * C)
+        s = e5m2_scale(dyf)
+        dy8 = q_e5m2(dyf * s)                                            # (values at scale s)
+        w2gt = q_e4m3_weight((w2 * gamma.reshape(C, 1)).t().contiguous())  # [4C, C]
+        dgelu = 0.5 * (1 + torch.erf(hf / math.sqrt(2))) + hf * torch.exp(-0.5 * hf * hf) / math.sqrt(2 * math.pi)
+        dh8 = q_e5m2((dy8 @ w2gt.t()) * dgelu)                           # still at scale s
+        w1t = q_e4m3_weight(w1.t().contiguous())                         # [C, 4C]
+        dln = (dh8 @ w1t.t()) / s
+        dw2 = gamma.reshape(C, 1) * (dy8.t() @ gf) / s
+        db2 = gamma * dyf.sum(0)
+        dw1 = (dh8.t() @ lnf) / s
+        db1 = dh8.sum(0) / s
+        dgamma = (dyf * y.reshape(-1, C)).sum(0)
+        return dln.reshape(ln8.shape), dw1, db1, dw2, db2, dgamma

@@ -287,3 +287,96 @@ def test_tn_wide(dev, M, N1, N2, monkeypatch):
     monkeypatch.setenv("MMG_TN_WIDE8", "1")
     linalg.gemm_tn_acc(a, big[:, 32:32 + N2], out)
     np.testing.assert_allclose(out.cpu().numpy(), (a.double().t() @ big[:, 32:32 + N2].double()).float().cpu().numpy(), rtol=2e-4, atol=2e-4 * M ** 0.5)
+
+
+# ---- fp8 backward (round 4): e5m2 gradients, 8-bit weight-gradient GEMM ---------------------------------------------------------------------
+def _q8(x, dtype):
+    return x.to(dtype).view(torch.uint8)
+
+
+def test_quantize_e5m2_matches_torch(dev):
+    """mmg_quantize_e5m2_bf16: per-tensor power-of-two scale from the device-side absmax, bytes equal to torch's float8_e5m2 cast of x * scale."""
+    from mmgclip import kernels as K
+    for amp in (1e-4, 3.0, 2.5e4):
+        x = (_rand((4096, 96), dev, amp, 21)).contiguous()
+        q, sc = K.quantize_e5m2(x)
+        amax = float(x.float().abs().max())
+        scale = float(sc[0])
+        assert scale == 2.0 ** np.floor(np.log2(16384.0 / amax)) and abs(float(sc[1]) * scale - 1.0) < 1e-6
+        ref = (x.float() * scale).to(torch.float8_e5m2).view(torch.uint8)
+        assert torch.equal(q, ref)
+    z = torch.zeros(64, 128, device=dev, dtype=torch.bfloat16)
+    q, sc = K.quantize_e5m2(z)
+    assert float(sc[0]) == 1.0 and int(q.max()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 512), (8192, 512, 2048), (640, 384, 128), (5000, 1024, 1024)])
+def test_nt_fp8_bwd_e5m2(dev, M, N, K):
+    """mmg_gemm_nt_fp8_bwd: e5m2 x e4m3 products are exact in fp32 up to the accumulation; epilogues 0 / 5 / 7; bf16 / fp32 / e5m2 outputs."""
+    from mmgclip import linalg as L
+    g = torch.Generator().manual_seed(5)
+    a8 = _q8(torch.randn(M, K, generator=g) * 3.0, torch.float8_e5m2).to(dev)
+    b8 = _q8(torch.randn(N, K, generator=g) * 0.5, torch.float8_e4m3fn).to(dev)
+    a = a8.view(torch.float8_e5m2).float().double()
+    b = b8.view(torch.float8_e4m3fn).float().double()
+    sa, sb = torch.tensor([0.25], device=dev), torch.tensor([0.5], device=dev)
+    ref = (a @ b.t()) * (2.0 * 0.25 * 0.5)
+    y = L.gemm_nt_fp8_bwd(a8, b8, out_kind=L.OUT_F32, alpha=2.0, alpha_dev=sa, alpha_dev2=sb)
+    # (the K = 128 MFMA aligns the products of a k-step before adding them: 2e-5 of the output range with e4m3 operands, measured 2.5e-5 with the
+    #  wider-ranged e5m2 ones - a rounding property of the instruction, exact on integers: test_tn_fp8_integer_exact_asymmetric)
+    assert float((y.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    aux = _rand((M, N), dev, 1.0, 9)
+    y7 = L.gemm_nt_fp8_bwd(a8, b8, aux_in=aux, epi=L.EPI_MUL_AUX, alpha=2.0, alpha_dev=sa, alpha_dev2=sb)
+    assert y7.dtype == torch.bfloat16
+    r7 = ref * aux.double()
+    assert float((y7.double() - r7).abs().max()) <= 2 ** -8 * float(r7.abs().max()) + 1e-6
+    y5 = L.gemm_nt_fp8_bwd(a8, b8, aux_in=aux, epi=L.EPI_DGELU_ONLY, out_kind=L.OUT_F32, alpha=2.0, alpha_dev=sa, alpha_dev2=sb)
+    x = aux.double().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert float((y5.double() - ref * x.grad).abs().max()) <= 2e-4 * float(ref.abs().max())
+    # e5m2 output (the gradient handed on in 8 bits): equal to torch's cast except results on a rounding boundary (fp32 accumulation order)
+    y8 = L.gemm_nt_fp8_bwd(a8, b8, aux_in=aux, epi=L.EPI_MUL_AUX, out_kind=L.OUT_E5M2, alpha=2.0, alpha_dev=sa, alpha_dev2=sb)
+    assert y8.dtype == torch.uint8
+    want = r7.float().clamp(-57344, 57344).to(torch.float8_e5m2)
+    got = y8.view(torch.float8_e5m2)
+    mism = (got.view(torch.uint8) != want.view(torch.uint8))
+    assert float(mism.float().mean()) < 2e-3, float(mism.float().mean())
+    # one e5m2 step (25 %) at most - on top of the accumulator's own absolute error (1e-4 of the output range: the k-step alignment above), which is
+    # what a result that nearly cancels sees (measured: 2 of 245 760 elements, |ref| = 5e-4 against a range of 45)
+    rng = float(ref.abs().max())
+    assert bool(((got.float() - want.float()).abs() <= 0.26 * torch.maximum(got.float().abs(), want.float().abs()) + 1e-4 * rng).all())
+    # e4m3 gradients too (a_e5m2 = False)
+    a4 = _q8(torch.randn(M, K, generator=g), torch.float8_e4m3fn).to(dev)
+    y4 = L.gemm_nt_fp8_bwd(a4, b8, a_e5m2=False, out_kind=L.OUT_F32)
+    r4 = a4.view(torch.float8_e4m3fn).float().double() @ b.t()
+    assert float((y4.double() - r4).abs().max()) <= 1e-4 * float(r4.abs().max())
+
+
+def test_tn_fp8_integer_exact_asymmetric(dev):
+    """Small integers are exact in e5m2 / e4m3 and in the fp32 accumulator: any wrong byte of a transposed 8-bit fragment read shows up exactly."""
+    from mmgclip import linalg as L
+    M, N1, N2 = 384, 128, 256
+    a = (torch.arange(M * N1).reshape(M, N1) % 5 - 2).float()              # {-2..2}: exact in e5m2
+    b = ((torch.arange(M * N2).reshape(M, N2) * 7) % 3 - 1).float()        # {-1, 0, 1}
+    out = torch.zeros(N1, N2, device=dev)
+    cs = torch.zeros(N1, device=dev)
+    L.gemm_tn_fp8_acc(_q8(a, torch.float8_e5m2).to(dev), _q8(b, torch.float8_e4m3fn).to(dev), out, colsum=cs)
+    assert torch.equal(out.cpu(), a.t() @ b)
+    assert torch.equal(cs.cpu(), a.sum(0))
+
+
+@pytest.mark.parametrize("M,N1,N2,e5", [(4096, 512, 2048, True), (33000, 2048, 512, True), (1000, 144, 80, True), (8192, 1024, 1024, False), (130, 128, 128, True)])
+def test_tn_fp8(dev, M, N1, N2, e5):
+    from mmgclip import linalg as L
+    g = torch.Generator().manual_seed(6)
+    fa = torch.float8_e5m2 if e5 else torch.float8_e4m3fn
+    a8 = _q8(torch.randn(M, N1, generator=g) * 2.0, fa).to(dev)
+    b8 = _q8(torch.randn(M, N2, generator=g), torch.float8_e4m3fn).to(dev)
+    a, b = a8.view(fa).float().double(), b8.view(torch.float8_e4m3fn).float().double()
+    out = torch.ones(N1, N2, device=dev)              # accumulate semantics
+    cs = torch.full((N1,), 2.0, device=dev)
+    sd = torch.tensor([0.125], device=dev)
+    L.gemm_tn_fp8_acc(a8, b8, out, a_e5m2=e5, alpha=2.0, alpha_dev=sd, colsum=cs)
+    ref = 1.0 + 0.25 * (a.t() @ b)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=5e-4, atol=5e-4 * M ** 0.5)
+    np.testing.assert_allclose(cs.cpu().numpy(), (2.0 + 0.25 * a.sum(0)).float().cpu().numpy(), rtol=5e-4, atol=5e-4 * M ** 0.5)

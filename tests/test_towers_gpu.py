@@ -114,7 +114,7 @@ def test_convnext_backward_on_the_saved_activation_equals_the_rebuilt_one(dev, m
 
 
 @pytest.mark.parametrize("variant,min_c", [("base", 1024), ("tiny", 768), ("base", 128), ("tiny", 384)])
-def test_convnext_fp8_forward_matches_the_fp8_oracle(dev, variant, min_c):
+def test_convnext_fp8_forward_matches_the_fp8_oracle(dev, variant, min_c, monkeypatch):
     """BASELINE config C5: e4m3 forward GEMMs (in every block with C % 128 == 0 and C >= min_c) against the oracle that rounds
     the same tensors to e4m3; the backward (bf16, straight through the rounding) against the oracle's STE gradients.
     An e4m3 step is 6-12 % of a value, so wherever the device's bf16 activations differ from the oracle's fp32 ones by a
@@ -123,6 +123,7 @@ def test_convnext_fp8_forward_matches_the_fp8_oracle(dev, variant, min_c):
     device must still be nearer to the e4m3 oracle than to the fp32 one.  Bit-level agreement is pinned block by block on
     identical inputs in tests/test_kernels_gpu.py::test_cnblock_fp8_forward_one_block."""
     from mmgclip.networks.encoder import ConvNextBaseEncoder, ConvNextTinyEncoder
+    monkeypatch.setenv("MMG_FP8_BWD", "0")          # (this test: the bf16 backward of rounds 1 - 3; the 8-bit backward has its own below)
     torch.manual_seed(0)
     tower = (ConvNextTinyEncoder if variant == "tiny" else ConvNextBaseEncoder)(micro_batch=2, fp8=True)
     tower.fp8_min_channels = min_c
@@ -159,6 +160,54 @@ def test_convnext_fp8_forward_matches_the_fp8_oracle(dev, variant, min_c):
             bad[name] = (r, c)
     measured("convnext_fp8_forward", variant=variant, min_c=min_c, feat_rel=r8, feat_cos=c8,
              grad_rel_max=max(v[0] for v in allg.values()), grad_cos_min=min(v[1] for v in allg.values()))
+    assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
+
+
+@pytest.mark.parametrize("variant,min_c", [("base", 1024), ("tiny", 384), ("base", 128)])
+def test_convnext_fp8_backward_matches_the_fp8_oracle(dev, variant, min_c):
+    """Round 4 (VERDICT r3 missing #2): the same blocks' BACKWARD in 8 bits - the incoming gradient cast to e5m2 with a per-tensor power-of-two
+    scale, both data-gradient GEMMs on e5m2 x e4m3 operands (dh handed on in e5m2, written once), both weight-gradient GEMMs on the 8-bit operands
+    (csrc/gemm_tn_fp8.hip) - against the oracle that rounds the same tensors at the same places (oracle.encoders_oracle.Fp8BlockMLP).  An e5m2 step
+    is 25 % of a value: element by element the device's gradient bytes and the oracle's flip across rounding boundaries wherever their bf16 / fp32
+    inputs differ by a fraction of a percent (the device's gradients are as far from the 8-bit oracle as that oracle is from the straight-through
+    one: the rounding noise of two runs is uncorrelated); what must agree are the sums the GEMMs form."""
+    from mmgclip.networks.encoder import ConvNextBaseEncoder, ConvNextTinyEncoder
+    torch.manual_seed(0)
+    tower = (ConvNextTinyEncoder if variant == "tiny" else ConvNextBaseEncoder)(micro_batch=2, fp8=True)
+    tower.fp8_min_channels = min_c
+    assert tower.fp8_bwd
+    last_stage_only = min_c == tower.dims[-1]
+    _randomize(tower, 1)
+    depths = (3, 3, 9, 3) if variant == "tiny" else (3, 3, 27, 3)
+    sd = {k[len("model."):]: v.clone() for k, v in tower.state_dict().items()}
+    img = torch.rand(2, 1, 64, 64, generator=torch.Generator().manual_seed(2))
+    wgt = torch.randn(2, tower.model_output_dimension, generator=torch.Generator().manual_seed(3))
+    grads = {}
+    for fb in (True, False):
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        pooled, _ = E.convnext_forward(osd, img, depths=depths, fp8_min_channels=min_c, fp8_backward=fb)
+        (pooled.flatten(1) * wgt).sum().backward()
+        grads[fb] = {k: v.grad for k, v in osd.items()}
+    tower = tower.to(dev)
+    feat = tower(img.to(dev))
+    assert sum(k.endswith(".w2gt8") for k in tower._wc) == sum(n for n, c in zip(depths, tower.dims) if c % 128 == 0 and c >= min_c)
+    r8, c8 = _rel(feat, pooled.flatten(1))
+    (feat * wgt.to(dev)).sum().backward()
+    bad, allg, nearer = {}, {}, 0
+    for name, p in tower.model.named_parameters():
+        r, c = _rel(p.grad, grads[True][name])
+        r_ste, _ = _rel(p.grad, grads[False][name])
+        allg[name] = (r, c)
+        nearer += r <= r_ste
+        # measured (profiles/r04_measured_tolerances.jsonl): last stage only 0.993 / 0.12; stages 3 - 4 of ConvNeXt-T 0.982 / 0.19; all 36 blocks of
+        # ConvNeXt-B 0.956 / 0.30 - the size of the 8-bit oracle's own distance from the straight-through one (0.10 / 0.19 / 0.21)
+        if not ((c > 0.99 and r < 0.15) if last_stage_only else (c > 0.94 and r < 0.35)):
+            bad[name] = (r, c)
+    q_effect = max(_rel(grads[True][n], grads[False][n])[0] for n in grads[True])
+    print("fp8 backward", variant, min_c, "grad rel max", max(v[0] for v in allg.values()), "cos min", min(v[1] for v in allg.values()),
+          "nearer to the 8-bit oracle than to the STE one:", nearer, "of", len(allg), "oracle 8-bit vs STE rel max", q_effect)
+    measured("convnext_fp8_backward", variant=variant, min_c=min_c, feat_rel=r8, grad_rel_max=max(v[0] for v in allg.values()),
+             grad_cos_min=min(v[1] for v in allg.values()), nearer_8bit_oracle=int(nearer), n_tensors=len(allg), oracle_8bit_vs_ste_rel_max=q_effect)
     assert not bad, f"{len(bad)} gradients off: {list(bad.items())[:8]}"
 
 
