@@ -280,6 +280,10 @@ int mmg_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, void* C, int
  * (amax fp32 [1] is scratch); scales fp32 [2] = (scale, 1 / scale).  n % 8 == 0.  The gradient entering a CNBlock backward
  * (torchvision CNBlock behind mmgclip/networks/encoder.py:53). */
 int mmg_quantize_e5m2_bf16(const void* src, long long n, float* amax, void* dst, float* scales, mmg_stream_t stream);
+/* The same in ONE pass ("delayed scaling"): scale = 2^floor(log2(4096 / *amax_prev)) from the absmax this tensor had at its previous quantisation
+ * (1 when that is 0), and the tensor's own absmax is left in amax_next (fp32 [1]) for the next call. */
+int mmg_quantize_e5m2_bf16_delayed(const void* src, long long n, const float* amax_prev, float* amax_next, void* dst, float* scales,
+                                   mmg_stream_t stream);
 /* C[M,N] = epilogue( alpha * alpha_dev * alpha_dev2 * A[M,K] B[N,K]^T ): A = e5m2 (a_e5m2 != 0) or e4m3 bytes, B e4m3 bytes, fp32 accumulate on the
  * K = 128 MFMA; epi 0 none | 5 multiply by GELU'(aux_in) | 7 multiply by aux_in (aux_in bf16 [M,N]); C bf16 / fp32 / e5m2 bytes (out_kind 0 / 1 / 3).
  * The two data-gradient GEMMs of a CNBlock (dh = (dy (gamma W2)) * GELU'(h) handed on in 8 bits, d LN-out = dh W1).  K % 128 == 0. */

@@ -95,3 +95,44 @@ MMG_API int mmg_quantize_e5m2_bf16(const void* src, long long n, float* amax, vo
     MMG_LAUNCH_CHECK("mmg_quantize_e5m2_bf16");
     return 0;
 }
+
+// Delayed scaling (one pass instead of two): the scale comes from the absmax this tensor had at its PREVIOUS quantisation (state[0]; the same block's
+// gradient of the previous micro-batch / step - gradient magnitudes move slowly), with 14 x headroom (target 4096 instead of 16384: e5m2's range is
+// 2^32, the low end has the room), and the pass records the new absmax in state[1] for the next call (the host swaps the two).  state[0] = 0: scale 1.
+__global__ __launch_bounds__(256) void quantize_e5m2_delayed_kernel(const uint4* __restrict__ src, size_t n8, const float* __restrict__ amax_prev,
+                                                                    unsigned* __restrict__ amax_next, uint2* __restrict__ dst, float* __restrict__ scales) {
+    const float a = *amax_prev;
+    float scale = 1.f;
+    if (a > 0.f && a < 3.0e38f) scale = exp2f(floorf(log2f(4096.f / a)));
+    if (a * scale > 4096.f) scale *= 0.5f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && scales) { scales[0] = scale; scales[1] = 1.f / scale; }
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 v = src[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned lo = (w[e] << 16) & 0x7fff0000u, hi = w[e] & 0x7fff0000u;
+            m = lo > m ? lo : m; m = hi > m ? hi : m;
+        }
+        dst[i] = make_uint2(pack4_e5m2(bf2f_lo(v.x) * scale, bf2f_hi(v.x) * scale, bf2f_lo(v.y) * scale, bf2f_hi(v.y) * scale),
+                            pack4_e5m2(bf2f_lo(v.z) * scale, bf2f_hi(v.z) * scale, bf2f_lo(v.w) * scale, bf2f_hi(v.w) * scale));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_next, m);
+}
+
+// As mmg_quantize_e5m2_bf16 with the scale taken from amax_prev (fp32 [1], device) and this tensor's own absmax left in amax_next (fp32 [1], zeroed here).
+MMG_API int mmg_quantize_e5m2_bf16_delayed(const void* src, long long n, const float* amax_prev, float* amax_next, void* dst, float* scales,
+                                           hipStream_t stream) {
+    MMG_CHECK_ARG(src && dst && amax_prev && amax_next && scales && n > 0 && n % 8 == 0, "mmg_quantize_e5m2_bf16_delayed: n=%lld must be a positive multiple of 8", n);
+    const size_t n8 = (size_t)n / 8;
+    int blocks = cdiv((long)n8, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (hipMemsetAsync(amax_next, 0, 4, stream) != hipSuccess) { mmg_set_error("mmg_quantize_e5m2_bf16_delayed: memset failed"); return 2; }
+    hipLaunchKernelGGL(quantize_e5m2_delayed_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, n8, amax_prev,
+                       reinterpret_cast<unsigned*>(amax_next), (uint2*)dst, scales);
+    MMG_LAUNCH_CHECK("mmg_quantize_e5m2_bf16_delayed");
+    return 0;
+}

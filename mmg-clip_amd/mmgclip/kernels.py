@@ -69,14 +69,23 @@ def layernorm_fwd_fp8(x, gamma, beta, eps, want_stats=True):
     return y, mean, rstd
 
 
-def quantize_e5m2(x):
+def quantize_e5m2(x, state=None):
     """bf16 tensor (numel % 8 == 0) -> (e5m2 bytes uint8 of x.shape, scales fp32 [2] = (scale, 1/scale)), per-tensor power-of-two scale from
-    the tensor's own absmax, computed and consumed on the device (the gradient operand of the fp8 backward, csrc/fp8_ops.hip)."""
+    the tensor's own absmax, computed and consumed on the device (the gradient operand of the fp8 backward, csrc/fp8_ops.hip).
+    `state` (a dict the caller keeps per tensor role): delayed scaling - the first call is the two-pass form above and records the absmax; later
+    calls take the scale from the previous call's absmax in one pass and record their own."""
     assert x.dtype == BF16 and x.is_contiguous()
     q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
     scales = torch.empty(2, device=x.device, dtype=torch.float32)
+    if state is not None and "amax" in state:
+        nxt = state["spare"]
+        call("mmg_quantize_e5m2_bf16_delayed", ptr(x), x.numel(), ptr(state["amax"]), ptr(nxt), ptr(q), ptr(scales), stream())
+        state["amax"], state["spare"] = nxt, state["amax"]
+        return q, scales
     amax = torch.empty(1, device=x.device, dtype=torch.float32)
     call("mmg_quantize_e5m2_bf16", ptr(x), x.numel(), ptr(amax), ptr(q), ptr(scales), stream())
+    if state is not None:
+        state["amax"], state["spare"] = amax, torch.zeros(1, device=x.device, dtype=torch.float32)
     return q, scales
 
 
@@ -157,9 +166,10 @@ def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0)
 def dwconv_mfma_pays(n, H, W, C, flip):
     """Where the matrix-core kernel beat the VALU one in the same-process A/B at the benchmark's batch (tools/dwm_scale.py, profiles/
     r04_dwconv_mfma_scale.txt, n = 256): few channel slabs (its persistent grid deals 32 workgroups per XCD group over C / 32 slabs: at C = 384 /
-    768 a quarter of them idle); the data gradient (+ residual operand) only at C = 96.  The rule reads the MAP size and the width only, never the
+    768 a quarter of them idle); the data gradient (+ residual operand) only up to C = 128 (ConvNeXt-B stage 1, tools/dwm_scale_b.py: -9 %; at
+    C = 256 / 512 / 1024 the VALU kernels win both directions).  The rule reads the MAP size and the width only, never the
     image count: a tower must take the same kernel whatever micro-batch it is run in (taps are rounded to bf16 here, kept fp32 there)."""
-    return H * W >= 96 * 96 and (C <= 96 if flip else C <= 192)
+    return H * W >= 96 * 96 and (C <= 128 if flip else C <= 192)
 
 
 def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None):

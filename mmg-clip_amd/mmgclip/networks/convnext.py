@@ -113,6 +113,8 @@ class ConvNextTower(nn.Module):
         # with a per-tensor power-of-two scale, both data-gradient GEMMs run on e5m2 x e4m3 operands (dh handed on in e5m2, written once), both
         # weight-gradient GEMMs on the 8-bit operands the forward / data path already hold (csrc/gemm_tn_fp8.hip)
         self.fp8_bwd = os.environ.get("MMG_FP8_BWD", "1") != "0"
+        self.fp8_delayed = os.environ.get("MMG_FP8_DELAYED", "1") != "0"      # gradient scale from the previous quantisation of the same tensor role
+        self._e5m2_state = {}
         # (round 4, with the 8-bit backward: 256 - same-box A/B of `bench.py --variant base --fp8 --checkpoint`: 925 ms/step from C = 256, 939 from 512,
         #  936 from 128: at C = 256 the GEMM pair's 4C-wide tensors are 8-bit in both directions now; rounds 1 - 3, forward only: no difference, 512)
         self.fp8_min_channels = int(os.environ.get("MMG_FP8_MIN_C", "256" if self.fp8_bwd else "512")) if fp8_min_channels is None else int(fp8_min_channels)
@@ -333,7 +335,8 @@ class ConvNextTower(nn.Module):
                     del ln, dh
                 elif g_saved is not None and g_saved.dtype == torch.uint8:
                     # 8-bit backward (config C5): hpre holds GELU'(h) (bf16), ln_saved / g_saved the e4m3 operands of the forward GEMMs
-                    dy8, sdy = K.quantize_e5m2(dx)
+                    # (delayed scaling from the second use on: the scale of this block's gradient comes from its previous quantisation - one pass)
+                    dy8, sdy = K.quantize_e5m2(dx, self._e5m2_state.setdefault(key, {}) if self.fp8_delayed else None)
                     dh8 = L.gemm_nt_fp8_bwd(dy8, wc[key + ".w2gt8"], aux_in=hpre, epi=L.EPI_MUL_AUX, out_kind=L.OUT_E5M2,
                                             alpha_dev=wc[key + ".s2gt"][1:])               # e5m2 at dy's scale: (acc / s_w) * GELU'
                     L.gemm_tn_fp8_acc(dy8, g_saved, tmp[key + ".dw2raw"], alpha_dev=sdy[1:])

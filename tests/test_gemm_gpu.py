@@ -308,6 +308,15 @@ def test_quantize_e5m2_matches_torch(dev):
     z = torch.zeros(64, 128, device=dev, dtype=torch.bfloat16)
     q, sc = K.quantize_e5m2(z)
     assert float(sc[0]) == 1.0 and int(q.max()) == 0
+    # delayed scaling: the first call of a state is the two-pass form; the second takes its scale from the first call's absmax (target 4096) in one pass
+    st = {}
+    x1, x2 = _rand((4096, 96), dev, 0.01, 22).contiguous(), _rand((4096, 96), dev, 0.03, 23).contiguous()
+    q1, s1 = K.quantize_e5m2(x1, st)
+    assert torch.equal(q1, K.quantize_e5m2(x1)[0]) and float(st["amax"]) == float(x1.float().abs().max())
+    q2, s2 = K.quantize_e5m2(x2, st)
+    scale2 = 2.0 ** np.floor(np.log2(4096.0 / float(x1.float().abs().max())))
+    assert float(s2[0]) == scale2 and float(st["amax"]) == float(x2.float().abs().max())
+    assert torch.equal(q2, (x2.float() * scale2).to(torch.float8_e5m2).view(torch.uint8))
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 2048, 512), (8192, 512, 2048), (640, 384, 128), (5000, 1024, 1024)])
