@@ -107,11 +107,18 @@ def test_c4_vit_b16_512_per_gpu_checkpointed(dev):
     assert peak < 200, peak          # fits the 288 GB part with room for BERT, optimizer state and the 2 GiB of pixels
 
 
-def test_c5_convnext_base_1024_per_gpu_fp8_checkpointed(dev):
-    """BASELINE C5 per-GPU share: 1024 images of 1024x1024 through ConvNeXt-B with e4m3 forward GEMMs + gradient checkpointing."""
+@pytest.mark.parametrize("delayed,tol_grad", [("0", 5e-3), ("1", 3e-2)])
+def test_c5_convnext_base_1024_per_gpu_fp8_checkpointed(dev, monkeypatch, delayed, tol_grad):
+    """BASELINE C5 per-GPU share: 1024 images of 1024x1024 through ConvNeXt-B with 8-bit GEMMs both ways + gradient checkpointing.
+
+    With the gradient scale taken from the tensor being quantised (MMG_FP8_DELAYED=0) every micro-batch of 64 is quantised alike in the
+    whole call and in the two halves, so the accumulated gradients agree as in bf16.  With delayed scaling (the default) the e5m2 scale
+    of a micro-batch comes from the amax of the PREVIOUS one of the same role, so the two runs differ by their history: a power-of-two
+    scale step moves some values by an e5m2 rounding (2^-3 relative each), measured 1.0e-2 on the worst parameter."""
     from mmgclip.networks.encoder import ConvNextBaseEncoder
+    monkeypatch.setenv("MMG_FP8_DELAYED", delayed)
     torch.manual_seed(0)
-    peak = _tower_split_equality(lambda: ConvNextBaseEncoder(micro_batch=64, checkpoint=True, fp8=True), 1024, 1024, 1024, dev, 1e-5, 5e-3)
+    peak = _tower_split_equality(lambda: ConvNextBaseEncoder(micro_batch=64, checkpoint=True, fp8=True), 1024, 1024, 1024, dev, 1e-5, tol_grad)
     assert peak < 200, peak
 
 
