@@ -12,15 +12,15 @@
 // What decides the speed is the LAYOUT CHANGE: the MFMA contracts over x, NHWC memory has the channel fastest.  Rounds 1-2 had this
 // formulation at parity with the VALU kernel because they scattered the halo tile into channel planes with 2- / 4-byte LDS stores and
 // wrote 8-byte pieces to HBM (profiles: MFMAs 30 us of 247 us).  Here both transposes are done by the LDS itself:
-//   in :  HBM --global_load_lds 16 B--> NHWC halo tile [22 x 22 pixels][32 ch]  --ds_read_b64_tr_b16 (4 pixels x 16 channels: lane =
-//         channel, 4 consecutive x)--> ds_write_b64 --> channel planes [32][22 rows][48 x] (96-byte rows: conflict-free ds_read_b128
-//         of the A-side... operand: lane = row, 8 consecutive x)
+//   in :  HBM --16-byte loads into registers, two items ahead--> ds_write_b128 --> NHWC halo tile [22 x 22 pixels][32 ch]
+//         --ds_read_b64_tr_b16 (4 pixels x 16 channels: lane = channel, 4 consecutive x)--> ds_write_b64 --> channel planes
+//         [32][22 rows][48 x] (96-byte rows: conflict-free ds_read_b128 of the data operand: lane = row, 8 consecutive x)
 //   out:  swapped MFMA (lane = row, 4 consecutive x_out) --ds_write_b64--> planes [32][16][16] --ds_read_b64_tr_b16 (4 channels x
 //         16 x: lane = pixel, 4 consecutive channels) x 2--> ds_write_b128 --> NHWC tile --ds_read_b128--> 16-byte global stores
 //         (+ the residual-gradient add of the data-gradient call)
-// One 8-wave workgroup per CU, persistent over the (image, tile) items of ONE 32-channel slab; a wave owns 4 channels and keeps their
-// 28 Toeplitz fragments (112 registers) for its whole life.  The NHWC halo tile is double buffered: the LDS-DMA of item k+1 runs under
-// the MFMA phase of item k.  Pitches (tools: bank model of MI355X_MICROARCH.md, LDS section): plane rows 96 B (b128 reads conflict-free under
+// One 16-wave (or 8-wave) workgroup per CU, persistent over the (image, tile) items of ONE 32-channel slab; a wave owns 2 (4) channels and
+// keeps their 14 (28) Toeplitz fragments (56 / 112 registers) for its whole life.  The halo tile of item k + 2 is in flight in registers
+// while item k is computed (see "Memory pipeline" below).  Pitches (tools: bank model of MI355X_MICROARCH.md, LDS section): plane rows 96 B (b128 reads conflict-free under
 // the real 16-lane grouping; 80 B is 2-way), planes 2128 B apart (b64 writes 2-way), output planes 40-byte rows / 656 B apart
 // (writes conflict-free, transposed reads 2-way), NHWC output pixels 80 B apart (b128 writes conflict-free).
 #include "common.h"

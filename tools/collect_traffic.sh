@@ -37,6 +37,11 @@ kernels = {}
 for k, (n, kb) in res["FETCH_SIZE"].items():
     w = res["WRITE_SIZE"].get(k, [0, 0.0])
     kernels[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * kb * 1024 / n, "write_bytes_per_launch": w[1] * 1024 / max(w[0], 1)}
+    # round 4 (tools/micro/fetch_calib.hip, profiles/r04_fetch_calib.txt): the x2 holds for requests of whole 128-byte lines; a kernel whose
+    # reads are 64-byte segments (a depthwise halo row of one 32-channel slab) is counted at x1 - its x2 figure is twice its traffic.  Both kept.
+    if k.startswith("dwconv7"):
+        kernels[k]["requests_64B"] = True
+        kernels[k]["fetch_bytes_per_launch_x1"] = kb * 1024 / n
 fam = collections.defaultdict(lambda: [0, 0.0])        # kernel family = symbol name without template arguments
 for k, v in kernels.items():
     v["hbm_bytes_per_launch"] = v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]
@@ -45,7 +50,8 @@ for k, v in kernels.items():
     fam[f][1] += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
 families = {f: {"launches": n, "hbm_bytes_per_launch": tot / n} for f, (n, tot) in fam.items() if n}
 summary = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-roofline",
-           "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE x1, KiB -> bytes",
+           "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE x1, KiB -> bytes; kernels flagged requests_64B read 64-byte segments, "
+                         "which FETCH_SIZE counts in full (profiles/r04_fetch_calib.txt): their traffic is fetch_bytes_per_launch_x1",
            "families": families, "kernels": kernels}
 json.dump(summary, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps({f: families[f] for f in ("gemm_nt_kernel", "gemm_tn_wide_kernel", "cnblock_mlp_fwd_kernel", "cnblock_bwdw_kernel") if f in families}))
