@@ -133,8 +133,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
     constexpr int H4 = Cfg::H4, KS = Cfg::KS, CT = Cfg::CT, RP = Cfg::RP, NP1 = Cfg::NP1, R = Cfg::R;
     constexpr int BW_THREADS = NW * 64, HS = H4 / NW, HT = HS / 16;
     static_assert(HS % 16 == 0 && (MODE == 1 || NW == 8), "hidden slice of a wave: whole 16-unit tiles; launch 2 is laid out for 8 waves");
-    static_assert(VAR == 0 || MODE == 1, "the resident-weight schedules are launch 1's");
-    constexpr bool RESW = VAR >= 1, PIPE = VAR >= 2;
+    // (launch 2: VAR bit 0 selects the ht-outer step order; the resident-weight schedules are launch 1's)
+    constexpr int VARX = VAR;
+    constexpr bool RESW = MODE == 1 && VAR >= 1, PIPE = MODE == 1 && VAR >= 2;
     constexpr bool W2 = MODE == 1, DX = MODE == 2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -395,9 +396,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
         {
             load_a(0); load_t(0);
             float dbsum[3] = {0.f, 0.f, 0.f};
+            // step order: launch 1 (rp outer) keeps the row fragments of an rp for its three steps; launch 2 re-reads its row fragments every step
+            // anyway (no registers to keep them), so it runs ht OUTER (MMG_BWDW_HTO, round 4): the two weight fragment sets of a hidden tile are
+            // fetched from L2 once per tile instead of once per row pair - half of the "load issue" segment of the phase probe (48 KiB per step and
+            // CU through the 64 B/clk vector-memory path) - at the price of the transposed xhat fragments being re-read from LDS every step
+            constexpr bool HTO = DX && (VARX & 1);
 #pragma unroll
             for (int st = 0; st < 2 * HT; ++st) {
-                const int rp = st / HT, ht = st % HT;
+                const int rp = HTO ? st % 2 : st / HT, ht = HTO ? st / 2 : st % HT;
                 if constexpr (W2 && RESW) {
                     // the NEXT tile's rows (requested after barrier A, 3 steps ago) go into the other image pair here, in the middle of this
                     // tile's P1: the LayerNorm statistics of waves 0-3 run beside their SIMD partners' GELU blocks instead of in front of a
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
                 if (st + 1 == 2 * HT) {
                     if (!RESW && tile + (int)gridDim.x < a.ntiles) load_w(0);      // next tile's first step: in flight over P2 / P3 / P0
                 } else {
-                    if (!RESW) load_w((st + 1) % HT);
+                    if (!RESW && (!HTO || rp == 1)) load_w(HTO ? ht + 1 : (st + 1) % HT);
                     if (W2 && ht == HT - 1) load_a(rp + 1);      // launch 1 keeps the row fragments of an rp for its three steps
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
                 // launch 2 (12 row fragments = 48 registers): re-requested for every step, AFTER the GELU block whose temporaries they
                 // would not fit beside, in flight under the six weight-gradient products
                 BWP_T(pr_s3);
-                if (DX && st + 1 < 2 * HT) load_a((st + 1) / HT);
+                if (DX && st + 1 < 2 * HT) load_a(HTO ? (st + 1) % 2 : (st + 1) / HT);
                 // weight gradient: k = the 32 rows of this pair of row tiles (slot 8 lg + j: j < 4 row 4 lg + j, else 16 + 4 lg + j - 4)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ht == HT - 1 && rp == 0) load_t(1);
+                if (HTO ? (st + 1 < 2 * HT) : (ht == HT - 1 && rp == 0)) load_t(HTO ? (st + 1) % 2 : 1);
                 BWP_T(pr_s4);
                 BWP_ADD(3, pr_s0, pr_s1); BWP_ADD(4, pr_s1, pr_s2); BWP_ADD(5, pr_s2, pr_s3); BWP_ADD(6, pr_s3, pr_s4);
             }
@@ -669,6 +675,7 @@ __global__ __launch_bounds__(256) void cnblock_bwdw_pack_kernel(const BwPack a) 
 }
 
 #define BW_DEFAULT_VAR 2
+#define BW_DEFAULT_HTO 1
 static int bw_cu_count() { return mmg_cu_count_cached(); }
 
 MMG_API int mmg_cnblock_bwdw_supported(int C) { return C == 96 ? 1 : 0; }
@@ -720,8 +727,15 @@ MMG_API int mmg_cnblock_bwdw(const void* dy, const void* xd, const float* ln_w, 
         mmg_allow_lds(cnblock_bwdw_kernel<96, 1, 8, 0>, Cfg::LDS);
         hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 1, 8, 0>), dim3(grid), dim3(512), Cfg::LDS, stream, a);
     }
-    mmg_allow_lds(cnblock_bwdw_kernel<96, 2, 8, 0>, Cfg::LDS);
-    hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 2, 8, 0>), dim3(grid), dim3(512), Cfg::LDS, stream, a);
+    const char* eh = getenv("MMG_BWDW_HTO");                 // (read per call: same-process A/B runs, tools/bwdw_bench.py)
+    const int hto = eh ? atoi(eh) : BW_DEFAULT_HTO;
+    if (hto) {
+        mmg_allow_lds(cnblock_bwdw_kernel<96, 2, 8, 1>, Cfg::LDS);
+        hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 2, 8, 1>), dim3(grid), dim3(512), Cfg::LDS, stream, a);
+    } else {
+        mmg_allow_lds(cnblock_bwdw_kernel<96, 2, 8, 0>, Cfg::LDS);
+        hipLaunchKernelGGL((cnblock_bwdw_kernel<96, 2, 8, 0>), dim3(grid), dim3(512), Cfg::LDS, stream, a);
+    }
     MMG_LAUNCH_CHECK("mmg_cnblock_bwdw");
     return 0;
 }

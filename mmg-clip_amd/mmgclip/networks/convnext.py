@@ -113,6 +113,7 @@ class ConvNextTower(nn.Module):
         # with a per-tensor power-of-two scale, both data-gradient GEMMs run on e5m2 x e4m3 operands (dh handed on in e5m2, written once), both
         # weight-gradient GEMMs on the 8-bit operands the forward / data path already hold (csrc/gemm_tn_fp8.hip)
         self.fp8_bwd = os.environ.get("MMG_FP8_BWD", "1") != "0"
+        self.fp8_bwd_now = False             # decided per forward (_decide_save_ln): the 8-bit operands are kept only while they fit
         self.fp8_delayed = os.environ.get("MMG_FP8_DELAYED", "1") != "0"      # gradient scale from the previous quantisation of the same tensor role
         self._e5m2_state = {}
         # (round 4, with the 8-bit backward: 256 - same-box A/B of `bench.py --variant base --fp8 --checkpoint`: 925 ms/step from C = 256, 939 from 512,
@@ -200,6 +201,17 @@ class ConvNextTower(nn.Module):
                 extra += self.depths[si] * n_alive * hh * ww * C * 2
             hh, ww = hh // 2, ww // 2
         total = torch.cuda.get_device_properties(device).total_memory
+        # 8-bit backward: its forward keeps the e4m3 LayerNorm output and activation (5 C bytes per row and block on top of the bf16 side output)
+        # - only while that stays below 15 % of the device memory (C5, checkpointed micro-batches of 64: 23 GB, on; ConvNeXt-B at 256 images
+        # without checkpointing: 93 GB on top of 267 GiB, off - that forward then saves what rounds 1 - 3 saved and its backward runs in bf16)
+        keep8, hh, ww = 0, H // 4, W // 4
+        for si in range(4):
+            C = self.dims[si]
+            if self.fp8 and self.fp8_bwd and C % 128 == 0 and C >= self.fp8_min_channels:
+                keep8 += self.depths[si] * n_alive * hh * ww * C * 5
+            hh, ww = hh // 2, ww // 2
+        mode8 = os.environ.get("MMG_FP8_BWD", "auto")
+        self.fp8_bwd_now = self.fp8 and self.fp8_bwd and (mode8 == "1" or keep8 <= 0.15 * total)
         if self.save_ln_mode in ("0", "1"):
             ln = self.save_ln_mode == "1"
         else:
@@ -256,7 +268,7 @@ class ConvNextTower(nn.Module):
                     # (8-bit backward: the side output is GELU'(h) - its data-gradient GEMM multiplies by it - and the e4m3 LayerNorm output /
                     #  activation are kept: they ARE the weight-gradient GEMMs' operands)
                     g = L.gemm_nt_fp8(ln, wc[key + ".w1f8"], bias=blk.block[3].bias.data, aux_out=hpre,
-                                      epi=L.EPI_GELU_DAUX if (save and key + ".w2gt8" in wc) else L.EPI_GELU,
+                                      epi=L.EPI_GELU_DAUX if (save and self.fp8_bwd_now and key + ".w2gt8" in wc) else L.EPI_GELU,
                                       out_kind=L.OUT_E4M3, alpha_dev=wc[key + ".s1"][1:])
                     xn = L.gemm_nt_fp8(g, wc[key + ".w2f8"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
                                        residual=x, alpha_dev=wc[key + ".s2"][1:])
@@ -267,7 +279,7 @@ class ConvNextTower(nn.Module):
                     xn = L.gemm_nt(g, wc[key + ".w2"], bias=blk.block[5].bias.data, colscale=blk.layer_scale.data.reshape(C),
                                    residual=x)
                 if save:                         # (an e4m3 LayerNorm output / activation is not what the bf16 backward reads: those are recomputed)
-                    if key + ".w2gt8" in wc:
+                    if self.fp8_bwd_now and key + ".w2gt8" in wc:
                         saved[key] = (x, d, mean, rstd, hpre, ln, g)         # (uint8 tensors: the 8-bit backward below)
                     else:
                         saved[key] = (x, d, mean, rstd, hpre, ln if (self.save_ln and ln.dtype == torch.bfloat16) else None,

@@ -50,11 +50,12 @@ def timed(fn, n=3):
     return s.elapsed_time(e) / n, out
 
 
-VARS = [v for v in os.environ.get("BWDW_VARS", "0,1,2").split(",") if v]      # launch-1 schedules (csrc/cnblock_bwdw.hip: VAR), same process
+VARS = [v for v in os.environ.get("BWDW_VARS", "0,2,2h").split(",") if v]      # launch-1 schedules (csrc/cnblock_bwdw.hip: VAR), same process
 
 
-def new_var(v):
-    os.environ["MMG_BWDW_VAR"] = v
+def new_var(v):        # "2h" = launch-1 schedule 2 + launch 2 in ht-outer step order (MMG_BWDW_HTO)
+    os.environ["MMG_BWDW_VAR"] = v.rstrip("h")
+    os.environ["MMG_BWDW_HTO"] = "1" if v.endswith("h") else "0"
     return new()
 
 
