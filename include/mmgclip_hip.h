@@ -284,6 +284,10 @@ int mmg_quantize_e5m2_bf16(const void* src, long long n, float* amax, void* dst,
  * (1 when that is 0), and the tensor's own absmax is left in amax_next (fp32 [1]) for the next call. */
 int mmg_quantize_e5m2_bf16_delayed(const void* src, long long n, const float* amax_prev, float* amax_next, void* dst, float* scales,
                                    mmg_stream_t stream);
+/* The delayed cast of a gradient MATRIX src bf16 [M, C] (contiguous) and colsum[c] += sum_m src[m][c] (fp32 [C]) in one pass over src: the bias gradient
+ * of a CNBlock's second Linear is taken from the bf16 gradient, not from its cast.  C = 16 x a divisor of 256 (256, 512, 1024 ... of ConvNeXt-B). */
+int mmg_quantize_e5m2_colsum_bf16(const void* src, int M, int C, const float* amax_prev, float* amax_next, void* dst, float* scales,
+                                  float* colsum, mmg_stream_t stream);
 /* C[M,N] = epilogue( alpha * alpha_dev * alpha_dev2 * A[M,K] B[N,K]^T ): A = e5m2 (a_e5m2 != 0) or e4m3 bytes, B e4m3 bytes, fp32 accumulate on the
  * K = 128 MFMA; epi 0 none | 5 multiply by GELU'(aux_in) | 7 multiply by aux_in (aux_in bf16 [M,N]); C bf16 / fp32 / e5m2 bytes (out_kind 0 / 1 / 3).
  * The two data-gradient GEMMs of a CNBlock (dh = (dy (gamma W2)) * GELU'(h) handed on in 8 bits, d LN-out = dh W1).  K % 128 == 0. */

@@ -136,3 +136,76 @@ MMG_API int mmg_quantize_e5m2_bf16_delayed(const void* src, long long n, const f
     MMG_LAUNCH_CHECK("mmg_quantize_e5m2_bf16_delayed");
     return 0;
 }
+
+// Delayed-scaling cast of a gradient matrix AND its column sums in one pass (round 4): the incoming gradient dy [M, C] of a CNBlock's MLP is read
+// once - e5m2 bytes out (16-byte stores: a thread owns 16 columns), its absmax for the next call, and colsum[c] += sum_m dy[m][c] (the bias
+// gradient of the block's second Linear, which the 8-bit weight-gradient GEMM takes from the bf16 gradient, not from its cast).  Replaces
+// mmg_quantize_e5m2_bf16_delayed + mmg_colsum_bf16 (two reads of dy).  C % 16 == 0 and 256 % (C / 16) == 0: a thread keeps its columns for all its rows.
+__global__ __launch_bounds__(256) void quantize_e5m2_colsum_kernel(const uint4* __restrict__ src, int M, int C, const float* __restrict__ amax_prev,
+                                                                   unsigned* __restrict__ amax_next, uint4* __restrict__ dst,
+                                                                   float* __restrict__ scales, float* __restrict__ colsum) {
+    extern __shared__ float q5_sums[];          // [C]
+    const float a = *amax_prev;
+    float scale = 1.f;
+    if (a > 0.f && a < 3.0e38f) scale = exp2f(floorf(log2f(4096.f / a)));
+    if (a * scale > 4096.f) scale *= 0.5f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && scales) { scales[0] = scale; scales[1] = 1.f / scale; }
+    for (int i = threadIdx.x; i < C; i += 256) q5_sums[i] = 0.f;
+    __syncthreads();
+    const int G = C / 16;                        // threads per row
+    const int cg = threadIdx.x % G;
+    const int rows_wg = 256 / G;                 // rows a workgroup covers per pass
+    const long stride = (long)gridDim.x * rows_wg;
+    float cs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+    unsigned m = 0;
+    auto one = [&](long r, const uint4 v0, const uint4 v1) {
+        const unsigned w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f0 = bf2f_lo(w[2 * e]), f1 = bf2f_hi(w[2 * e]), f2 = bf2f_lo(w[2 * e + 1]), f3 = bf2f_hi(w[2 * e + 1]);
+            cs[4 * e] += f0; cs[4 * e + 1] += f1; cs[4 * e + 2] += f2; cs[4 * e + 3] += f3;
+            o[e] = pack4_e5m2(f0 * scale, f1 * scale, f2 * scale, f3 * scale);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned lo = (w[e] << 16) & 0x7fff0000u, hi = w[e] & 0x7fff0000u;
+            m = lo > m ? lo : m; m = hi > m ? hi : m;
+        }
+        dst[r * G + cg] = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    long r = (long)blockIdx.x * rows_wg + threadIdx.x / G;
+    for (; r + stride < M; r += 2 * stride) {                      // two rows (four 16-byte loads) in flight per thread
+        const uint4 a0 = src[(r * G + cg) * 2], a1 = src[(r * G + cg) * 2 + 1];
+        const uint4 b0 = src[((r + stride) * G + cg) * 2], b1 = src[((r + stride) * G + cg) * 2 + 1];
+        one(r, a0, a1);
+        one(r + stride, b0, b1);
+    }
+    if (r < M) one(r, src[(r * G + cg) * 2], src[(r * G + cg) * 2 + 1]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) atomicAdd(&q5_sums[cg * 16 + e], cs[e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_next, m);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(colsum + i, q5_sums[i]);
+}
+
+MMG_API int mmg_quantize_e5m2_colsum_bf16(const void* src, int M, int C, const float* amax_prev, float* amax_next, void* dst, float* scales,
+                                          float* colsum, hipStream_t stream) {
+    MMG_CHECK_ARG(src && dst && amax_prev && amax_next && scales && colsum && M > 0, "mmg_quantize_e5m2_colsum_bf16: null pointer or M=%d", M);
+    MMG_CHECK_ARG(C >= 16 && C % 16 == 0 && C <= 4096 && 256 % (C / 16) == 0,
+                  "mmg_quantize_e5m2_colsum_bf16: C=%d must be 16 x a divisor of 256 (16 ... 4096)", C);
+    const int rows_wg = 256 / (C / 16);
+    int blocks = cdiv(M, rows_wg * 8);            // >= 8 rows per thread
+    const int cap = 4 * mmg_cu_count_cached();
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (hipMemsetAsync(amax_next, 0, 4, stream) != hipSuccess) { mmg_set_error("mmg_quantize_e5m2_colsum_bf16: memset failed"); return 2; }
+    hipLaunchKernelGGL(quantize_e5m2_colsum_kernel, dim3(blocks), dim3(256), C * sizeof(float), stream, (const uint4*)src, M, C, amax_prev,
+                       reinterpret_cast<unsigned*>(amax_next), (uint4*)dst, scales, colsum);
+    MMG_LAUNCH_CHECK("mmg_quantize_e5m2_colsum_bf16");
+    return 0;
+}

@@ -69,19 +69,30 @@ def layernorm_fwd_fp8(x, gamma, beta, eps, want_stats=True):
     return y, mean, rstd
 
 
-def quantize_e5m2(x, state=None):
+def quantize_e5m2(x, state=None, colsum=None):
     """bf16 tensor (numel % 8 == 0) -> (e5m2 bytes uint8 of x.shape, scales fp32 [2] = (scale, 1/scale)), per-tensor power-of-two scale from
     the tensor's own absmax, computed and consumed on the device (the gradient operand of the fp8 backward, csrc/fp8_ops.hip).
     `state` (a dict the caller keeps per tensor role): delayed scaling - the first call is the two-pass form above and records the absmax; later
-    calls take the scale from the previous call's absmax in one pass and record their own."""
+    calls take the scale from the previous call's absmax in one pass and record their own.
+    `colsum` (fp32 [C], x 2-D): += x.sum(0) as well - in the same pass over x where the delayed form allows it (MMG_FP8_FUSED_CAST=0: never)."""
     assert x.dtype == BF16 and x.is_contiguous()
     q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
     scales = torch.empty(2, device=x.device, dtype=torch.float32)
     if state is not None and "amax" in state:
         nxt = state["spare"]
-        call("mmg_quantize_e5m2_bf16_delayed", ptr(x), x.numel(), ptr(state["amax"]), ptr(nxt), ptr(q), ptr(scales), stream())
+        C = x.shape[-1]
+        if colsum is not None and x.dim() == 2 and C % 16 == 0 and C <= 4096 and 256 % (C // 16) == 0 \
+                and os.environ.get("MMG_FP8_FUSED_CAST", "1") != "0":
+            call("mmg_quantize_e5m2_colsum_bf16", ptr(x), x.shape[0], C, ptr(state["amax"]), ptr(nxt), ptr(q), ptr(scales), ptr(colsum), stream())
+            colsum = None
+        else:
+            call("mmg_quantize_e5m2_bf16_delayed", ptr(x), x.numel(), ptr(state["amax"]), ptr(nxt), ptr(q), ptr(scales), stream())
         state["amax"], state["spare"] = nxt, state["amax"]
+        if colsum is not None:
+            call("mmg_colsum_bf16", ptr(x), x.stride(0), x.shape[0], C, ptr(colsum), stream())
         return q, scales
+    if colsum is not None:
+        call("mmg_colsum_bf16", ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(colsum), stream())
     amax = torch.empty(1, device=x.device, dtype=torch.float32)
     call("mmg_quantize_e5m2_bf16", ptr(x), x.numel(), ptr(amax), ptr(q), ptr(scales), stream())
     if state is not None:

@@ -348,11 +348,11 @@ class ConvNextTower(nn.Module):
                 elif g_saved is not None and g_saved.dtype == torch.uint8:
                     # 8-bit backward (config C5): hpre holds GELU'(h) (bf16), ln_saved / g_saved the e4m3 operands of the forward GEMMs
                     # (delayed scaling from the second use on: the scale of this block's gradient comes from its previous quantisation - one pass)
-                    dy8, sdy = K.quantize_e5m2(dx, self._e5m2_state.setdefault(key, {}) if self.fp8_delayed else None)
+                    # (+ the bias gradient of the second Linear = column sums of the bf16 gradient itself, in the same pass over it)
+                    dy8, sdy = K.quantize_e5m2(dx, self._e5m2_state.setdefault(key, {}) if self.fp8_delayed else None, colsum=tmp[key + ".db2raw"])
                     dh8 = L.gemm_nt_fp8_bwd(dy8, wc[key + ".w2gt8"], aux_in=hpre, epi=L.EPI_MUL_AUX, out_kind=L.OUT_E5M2,
                                             alpha_dev=wc[key + ".s2gt"][1:])               # e5m2 at dy's scale: (acc / s_w) * GELU'
                     L.gemm_tn_fp8_acc(dy8, g_saved, tmp[key + ".dw2raw"], alpha_dev=sdy[1:])
-                    L.colsum_acc(dx, tmp[key + ".db2raw"])                                  # (the bias gradient from the bf16 gradient itself)
                     L.gemm_tn_fp8_acc(dh8, ln_saved, gname(blk.block[3], "weight"), alpha_dev=sdy[1:], colsum=gname(blk.block[3], "bias"))
                     dln = L.gemm_nt_fp8_bwd(dh8, wc[key + ".w1t8"], alpha_dev=wc[key + ".s1t"][1:], alpha_dev2=sdy[1:])
                     del dh8, dy8
@@ -466,12 +466,15 @@ class _ConvNextFn(torch.autograd.Function):
             tower.save_ln = tower._decide_save_ln(min(mb, images.shape[0]) if ckpt else images.shape[0], images.shape[-2], images.shape[-1],
                                                   images.device)
         for i in range(0, images.shape[0], mb):
-            ft, sv = tower._forward_mb(images[i:i + mb], save and not ckpt)
-            feats.append(ft)
             # gradient checkpointing at micro-batch granularity: keep only the pixels, re-run the micro-batch's forward (with its
-            # activations saved) right before its backward - activation memory becomes one micro-batch instead of the whole batch
-            saved.append({"recompute": images[i:i + mb]} if ckpt else sv)
-        ctx.tower, ctx.saved_mb = tower, saved if save else None
+            # activations saved) right before its backward - activation memory becomes one micro-batch instead of the whole batch.
+            # The LAST micro-batch keeps its activations (round 4): the backward starts with it (reverse order), so still only one
+            # micro-batch's activations are alive at any time, and one of the n recomputations is not run (MMG_CKPT_KEEP_LAST=0: all are).
+            keep = ckpt and i + mb >= images.shape[0] and os.environ.get("MMG_CKPT_KEEP_LAST", "1") != "0"
+            ft, sv = tower._forward_mb(images[i:i + mb], save and (not ckpt or keep))
+            feats.append(ft)
+            saved.append({"recompute": images[i:i + mb]} if (ckpt and not keep) else sv)
+        ctx.tower, ctx.saved_mb, ctx.reverse = tower, saved if save else None, ckpt
         return torch.cat(feats, 0) if len(feats) > 1 else feats[0]
 
     @staticmethod
@@ -480,15 +483,20 @@ class _ConvNextFn(torch.autograd.Function):
         tower._arena.prepare_grads()
         tmp = tower._alloc_tmp(dfeat.device)
         dfeat = dfeat.float().contiguous()
-        i = 0
-        for k, sv in enumerate(ctx.saved_mb):
+        sizes = [sv["recompute"].shape[0] if "recompute" in sv else sv["shape"][0] for sv in ctx.saved_mb]
+        starts = [sum(sizes[:k]) for k in range(len(sizes))]
+        order = list(range(len(sizes)))
+        if ctx.reverse:                      # checkpointing: the micro-batch whose activations were kept (the last one) first
+            order.reverse()
+        for pos, k in enumerate(order):
+            sv = ctx.saved_mb[k]
             if "recompute" in sv:
                 _, sv = tower._forward_mb(sv["recompute"], True)
-            n = sv["shape"][0]
-            final = k == len(ctx.saved_mb) - 1
+            i, n = starts[k], sizes[k]
+            final = pos == len(order) - 1
             tower._backward_mb(dfeat[i:i + n].contiguous(), sv, tmp, final=final, announce=final and last_backward(tower))
             sv.clear()
-            i += n
+            ctx.saved_mb[k] = None
         ctx.saved_mb = None
         backward_finished(tower)
         return None, None, None

@@ -10,6 +10,8 @@ All layers reuse the BERT/ConvNeXt kernels: the 16x16/16 patch convolution is `m
 `mmg_attention_fwd/bwd` without a key mask (whole sequence in LDS) up to S = 256 tokens (224x224 -> 197) and the
 flash-style tiled `mmg_attention_long_fwd/bwd` beyond (1024x1024 -> S = 4097, BASELINE config C4).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -199,10 +201,13 @@ class _ViTFn(torch.autograd.Function):
         ckpt = save and tower.checkpoint
         feats, saved = [], []
         for i in range(0, images.shape[0], tower.micro_batch):
-            ft, sv = tower._forward_mb(images[i:i + tower.micro_batch], save and not ckpt)
+            # (the last micro-batch keeps its activations and is the first one the backward takes: one recomputation less, still one
+            #  micro-batch of activations alive at a time - MMG_CKPT_KEEP_LAST=0 recomputes all)
+            keep = ckpt and i + tower.micro_batch >= images.shape[0] and os.environ.get("MMG_CKPT_KEEP_LAST", "1") != "0"
+            ft, sv = tower._forward_mb(images[i:i + tower.micro_batch], save and (not ckpt or keep))
             feats.append(ft)
-            saved.append({"recompute": images[i:i + tower.micro_batch], "B": ft.shape[0]} if ckpt else sv)
-        ctx.tower, ctx.saved_mb = tower, saved if save else None
+            saved.append({"recompute": images[i:i + tower.micro_batch], "B": ft.shape[0]} if (ckpt and not keep) else sv)
+        ctx.tower, ctx.saved_mb, ctx.reverse = tower, saved if save else None, ckpt
         return torch.cat(feats, 0) if len(feats) > 1 else feats[0]
 
     @staticmethod
@@ -210,12 +215,17 @@ class _ViTFn(torch.autograd.Function):
         tower = ctx.tower
         tower._arena.prepare_grads()
         dfeat = dfeat.float().contiguous()
-        i = 0
-        for sv in ctx.saved_mb:
+        sizes = [sv["B"] for sv in ctx.saved_mb]
+        starts = [sum(sizes[:k]) for k in range(len(sizes))]
+        order = list(range(len(sizes)))
+        if ctx.reverse:
+            order.reverse()
+        for k in order:
+            sv = ctx.saved_mb[k]
             if "recompute" in sv:
                 _, sv = tower._forward_mb(sv["recompute"], True)
-            tower._backward_mb(dfeat[i:i + sv["B"]].contiguous(), sv)
-            i += sv["B"]
+            tower._backward_mb(dfeat[starts[k]:starts[k] + sizes[k]].contiguous(), sv)
+            ctx.saved_mb[k] = None
         ctx.saved_mb = None
         backward_finished(tower)
         return None, None, None

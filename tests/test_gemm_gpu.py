@@ -319,6 +319,29 @@ def test_quantize_e5m2_matches_torch(dev):
     assert torch.equal(q2, (x2.float() * scale2).to(torch.float8_e5m2).view(torch.uint8))
 
 
+@pytest.mark.parametrize("M,C", [(4096, 512), (777, 256), (1, 1024), (5001, 2048), (300, 96)])
+def test_quantize_e5m2_with_column_sums_in_one_pass(dev, M, C, monkeypatch):
+    """mmg_quantize_e5m2_colsum_bf16 (delayed cast + bias-gradient column sums in one read of the gradient): the same bytes, scale and recorded
+    absmax as the separate delayed cast, column sums ADDED to what the buffer held; widths the fused kernel does not take (96) fall back to the two
+    kernels inside the same host call."""
+    from mmgclip import kernels as K
+    x0, x1 = _rand((M, C), dev, 0.02, 31).contiguous(), _rand((M, C), dev, 0.05, 32).contiguous()
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MMG_FP8_FUSED_CAST", fused)
+        st = {}
+        cs = torch.full((C,), 2.0, device=dev)
+        K.quantize_e5m2(x0, st, colsum=cs)                       # first use of a state: two-pass cast + separate column sums
+        q, sc = K.quantize_e5m2(x1, st, colsum=cs)               # delayed form
+        out[fused] = (q, sc.clone(), float(st["amax"]), cs)
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1]) and out["1"][2] == out["0"][2]
+    assert out["1"][2] == float(x1.float().abs().max())
+    ref = 2.0 + x0.double().sum(0) + x1.double().sum(0)
+    for fused in ("1", "0"):
+        err = float((out[fused][3].double() - ref).abs().max())
+        assert err < 1e-4 * (1.0 + float(ref.abs().max())), (fused, err)      # fp32 sums, different orders
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 2048, 512), (8192, 512, 2048), (640, 384, 128), (5000, 1024, 1024)])
 def test_nt_fp8_bwd_e5m2(dev, M, N, K):
     """mmg_gemm_nt_fp8_bwd: e5m2 x e4m3 products are exact in fp32 up to the accumulation; epilogues 0 / 5 / 7; bf16 / fp32 / e5m2 outputs."""
