@@ -384,9 +384,12 @@ def test_nt_fp8_bwd_e5m2(dev, M, N, K):
     assert float((y4.double() - r4).abs().max()) <= 1e-4 * float(r4.abs().max())
 
 
-def test_tn_fp8_integer_exact_asymmetric(dev):
-    """Small integers are exact in e5m2 / e4m3 and in the fp32 accumulator: any wrong byte of a transposed 8-bit fragment read shows up exactly."""
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_tn_fp8_integer_exact_asymmetric(dev, monkeypatch, wide):
+    """Small integers are exact in e5m2 / e4m3 and in the fp32 accumulator: any wrong byte of a transposed 8-bit fragment read shows up exactly
+    (both tilings of csrc/gemm_tn_fp8.hip: 128 x 128 and 256 x 256, the second forced onto a shape with partial tiles)."""
     from mmgclip import linalg as L
+    monkeypatch.setenv("MMG_TN8_WIDE", wide)
     M, N1, N2 = 384, 128, 256
     a = (torch.arange(M * N1).reshape(M, N1) % 5 - 2).float()              # {-2..2}: exact in e5m2
     b = ((torch.arange(M * N2).reshape(M, N2) * 7) % 3 - 1).float()        # {-1, 0, 1}
@@ -397,9 +400,14 @@ def test_tn_fp8_integer_exact_asymmetric(dev):
     assert torch.equal(cs.cpu(), a.sum(0))
 
 
-@pytest.mark.parametrize("M,N1,N2,e5", [(4096, 512, 2048, True), (33000, 2048, 512, True), (1000, 144, 80, True), (8192, 1024, 1024, False), (130, 128, 128, True)])
-def test_tn_fp8(dev, M, N1, N2, e5):
+@pytest.mark.parametrize("wide", ["auto", "0", "1"])
+@pytest.mark.parametrize("M,N1,N2,e5", [(4096, 512, 2048, True), (33000, 2048, 512, True), (1000, 144, 80, True), (8192, 1024, 1024, False), (130, 128, 128, True),
+                                        (20000, 384, 1536, True)])
+def test_tn_fp8(dev, monkeypatch, M, N1, N2, e5, wide):
+    """8-bit weight-gradient GEMM against fp64 products of the same bytes; `wide` = which tiling (auto: 256 x 256 from 256-wide outputs and 8 192 rows)."""
     from mmgclip import linalg as L
+    if wide != "auto":
+        monkeypatch.setenv("MMG_TN8_WIDE", wide)
     g = torch.Generator().manual_seed(6)
     fa = torch.float8_e5m2 if e5 else torch.float8_e4m3fn
     a8 = _q8(torch.randn(M, N1, generator=g) * 2.0, fa).to(dev)

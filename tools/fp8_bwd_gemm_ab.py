@@ -50,3 +50,13 @@ for M, C in ((262144, 512), (65536, 1024)):
     u3 = timed(lambda: L.gemm_tn_fp8_acc(dy8, gact8, dW2, alpha_dev=sdy[1:]))
     u4 = timed(lambda: L.gemm_tn_fp8_acc(dh8, ln8, dW1, alpha_dev=sdy[1:], colsum=db))
     print(f"M={M} C={C} 8-bit: dh {u1:7.1f}  dln {u2:7.1f}  dW2 {u3:7.1f}  dW1 {u4:7.1f}  quantize dy {t_q:6.1f}  sum {u1 + u2 + u3 + u4 + t_q:8.1f} us", flush=True)
+    # the weight-gradient kernel's forms (csrc/gemm_tn_fp8.hip): 128 x 128 tiles on a (tile, chunk) grid, the same with a row chunk's tiles on one XCD, 256 x 256 tiles
+    for tag, env in (("128 grid", {"MMG_TN8_WIDE": "0", "MMG_TN8_XCD": "0"}), ("128 xcd ", {"MMG_TN8_WIDE": "0", "MMG_TN8_XCD": "1"}), ("256 xcd ", {"MMG_TN8_WIDE": "1"})):
+        for k in ("MMG_TN8_WIDE", "MMG_TN8_XCD"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        v3 = timed(lambda: L.gemm_tn_fp8_acc(dy8, gact8, dW2, alpha_dev=sdy[1:]))
+        v4 = timed(lambda: L.gemm_tn_fp8_acc(dh8, ln8, dW1, alpha_dev=sdy[1:], colsum=db))
+        print(f"    weight-gradient kernel {tag}: dW2 {v3:7.1f}  dW1 {v4:7.1f} us", flush=True)
+    for k in ("MMG_TN8_WIDE", "MMG_TN8_XCD"):
+        os.environ.pop(k, None)
