@@ -46,6 +46,62 @@ __device__ __forceinline__ bf16x8 att_tr_frag(const char* img, int t0, int dt, i
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// The same fragment(s) for the TILED kernels, which keep the next tile's LDS-DMA in flight while they read this one: issued as inline assembly,
+// because hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr BUILTIN whenever an LDS-DMA is outstanding (it cannot tell the two
+// halves of the double buffer apart; plain ds_read_b128 does not get that wait) - which drained the prefetch in the middle of every tile (round 4,
+// found in csrc/gemm_tn_fp8.hip; same finding as gemm_tn_wide.hip in round 2).  The wait for the data is inside the block: the compiler sees
+// finished registers.  Two fragments per block (four reads in flight) where a step needs two.
+// Top of a tile iteration in the tiled kernels: the tile requested one iteration ago must have LANDED in LDS before anyone reads it.  __syncthreads()
+// does not wait for it - a workgroup-scope fence does not drain the vector-memory counter - and until round 4 the only wait for the DMA in these loops
+// was the `s_waitcnt vmcnt(0)` hipcc happens to put in front of the ds_read_tr BUILTIN; with the transposed reads issued as inline assembly (below)
+// nothing waited at all, and workgroups read tiles that had not arrived (LSE and context off by rounding-size errors, run to run - found by
+// tools/att_check.py).  Explicit now: every wave waits for its own DMA pieces, then the barrier.
+__device__ __forceinline__ void att_tile_landed() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+__device__ __forceinline__ unsigned att_lds_addr(const char* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void att_tr_addr(const char* img, int t0, int dt, int lane, unsigned& a0, unsigned& a1) {
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
+    const int ra = t0 + 4 * g + q4, rb = ra + 16;
+    const int c = dt * 2 + (p >> 1);
+    a0 = att_lds_addr(img + att_off(ra, c) + (p & 1) * 8);
+    a1 = att_lds_addr(img + att_off(rb, c) + (p & 1) * 8);
+}
+__device__ __forceinline__ bf16x8 att_tr_frag_tiled(const char* img, int t0, int dt, int lane) {
+    unsigned a0, a1;
+    att_tr_addr(img, t0, dt, lane, a0, a1);
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ void att_tr_frag2_tiled(const char* imgA, const char* imgB, int t0, int dt, int lane, bf16x8& fa, bf16x8& fb) {
+    unsigned a0, a1, b0, b1;
+    att_tr_addr(imgA, t0, dt, lane, a0, a1);
+    att_tr_addr(imgB, t0, dt, lane, b0, b1);
+    bf16x4 alo, ahi, blo, bhi;
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(alo), "=&v"(ahi), "=&v"(blo), "=&v"(bhi) : "v"(a0), "v"(a1), "v"(b0), "v"(b1) : "memory");
+    fa = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+    fb = bf16x8{blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+}
+
+// MMG build knob (A/B, tools/build_ab_lib.sh ... -DATT_ASM_TR=1): the tiled kernels' transposed reads as inline assembly (no compiler-inserted
+// vmcnt(0) in front of them; LDS latency exposed per fragment instead) or through the builtin (default: measured faster, profiles/r04_attn_tr_ab.txt)
+#ifndef ATT_ASM_TR
+#define ATT_ASM_TR 0
+#endif
+#if ATT_ASM_TR
+#define ATT_TR1(img, t0, dt, lane) att_tr_frag_tiled(img, t0, dt, lane)
+#define ATT_TR2(ia, ib, t0, dt, lane, fa, fb) att_tr_frag2_tiled(ia, ib, t0, dt, lane, fa, fb)
+#else
+#define ATT_TR1(img, t0, dt, lane) att_tr_frag(img, t0, dt, lane)
+#define ATT_TR2(ia, ib, t0, dt, lane, fa, fb) do { fa = att_tr_frag(ia, t0, dt, lane); fb = att_tr_frag(ib, t0, dt, lane); } while (0)
+#endif
+
 __device__ __forceinline__ bf16x8 pack_frag(const f32x4 a, const f32x4 b) {
     bf16x8 r;
     r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
@@ -571,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const AttArgs a)
     att_stage_dma(base + 2 * a.Hd, a.ld, KV[0][1], 0, a.S);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * ATT_TILE;
-        __syncthreads();       // tile kt has landed (vmcnt(0) of every wave) and nobody still reads the other buffer
+        att_tile_landed();     // tile kt has landed (explicit vmcnt(0) of every wave) and nobody still reads the other buffer
         if (kt + 1 < ntiles) {
             att_stage_dma(base + a.Hd, a.ld, KV[(kt + 1) & 1][0], k0 + ATT_TILE, a.S);
             att_stage_dma(base + 2 * a.Hd, a.ld, KV[(kt + 1) & 1][1], k0 + ATT_TILE, a.S);
@@ -638,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_fwd_kernel(const AttArgs a)
             for (int rb = 0; rb < RB; ++rb) pf[rb] = pack_frag(sc[rb][2 * c], sc[rb][2 * c + 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 vt = att_tr_frag(Vs, c * 32, dt, lane);
+                const bf16x8 vt = ATT_TR1(Vs, c * 32, dt, lane);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) o[rb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf[rb], o[rb][dt], 0, 0, 0);
             }
@@ -724,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const AttArgs a, 
     att_stage_dma(base + 2 * a.Hd, a.ld, KV[0][1], 0, a.S);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * ATT_TILE;
-        __syncthreads();
+        att_tile_landed();
         if (kt + 1 < ntiles) {
             att_stage_dma(base + a.Hd, a.ld, KV[(kt + 1) & 1][0], k0 + ATT_TILE, a.S);
             att_stage_dma(base + 2 * a.Hd, a.ld, KV[(kt + 1) & 1][1], k0 + ATT_TILE, a.S);
@@ -770,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dq_kernel(const AttArgs a, 
             for (int rb = 0; rb < RB; ++rb) dsf[rb] = pack_frag(ds[rb][0], ds[rb][1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 kt_f = att_tr_frag(Ks, c * 32, dt, lane);
+                const bf16x8 kt_f = ATT_TR1(Ks, c * 32, dt, lane);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) dq[rb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[rb], dq[rb][dt], 0, 0, 0);
             }
@@ -834,15 +890,17 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkv_kernel(const AttArgs a,
     }
     for (int qt = 0; qt < ntiles; ++qt) {
         const int qn = (qt + 1) * ATT_TILE;
-        __syncthreads();
-        float nl = 1.0e30f, nd = 0.f;
+        att_tile_landed();
+        // next tile's row statistics: loaded by every thread from a clamped address and SELECTED where they are stored, at the end of the
+        // iteration - a load under `if (thread < 64) if (q < S)` is merged with its default at the end of the branch, and that merge is a use:
+        // hipcc waited there with vmcnt(0), i.e. for the LDS-DMA issued just above, in every iteration (round 4)
+        // (unconditional too - past the last tile the clamped address re-reads the last row: a value set under `if (qt + 1 < ntiles)` is merged
+        //  with its default right after the branch, the same use)
+        const size_t qi = srow + min(qn + (int)(threadIdx.x & (ATT_TILE - 1)), a.S - 1);
+        const float nl = a.lse[qi], nd = delta[qi];
         if (qt + 1 < ntiles) {
             att_stage_dma(base, a.ld, QG[(qt + 1) & 1][0], qn, a.S);
             att_stage_dma(gbase, a.lddc, QG[(qt + 1) & 1][1], qn, a.S);
-            if (threadIdx.x < ATT_TILE) {
-                const int q = qn + threadIdx.x;
-                if (q < a.S) { nl = a.lse[srow + q] * ATT_LOG2E; nd = delta[srow + q]; }
-            }
         }
         const char* Qs = QG[qt & 1][0];
         const char* Gs = QG[qt & 1][1];
@@ -878,7 +936,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkv_kernel(const AttArgs a,
             for (int rb = 0; rb < RB; ++rb) { pf[rb] = pack_frag(pp[rb][0], pp[rb][1]); dsf[rb] = pack_frag(ds[rb][0], ds[rb][1]); }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 gt = att_tr_frag(Gs, c * 32, dt, lane), qt_f = att_tr_frag(Qs, c * 32, dt, lane);
+                bf16x8 gt, qt_f;
+                ATT_TR2(Gs, Qs, c * 32, dt, lane, gt, qt_f);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
                     dv[rb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf[rb], dv[rb][dt], 0, 0, 0);
@@ -887,8 +946,9 @@ __global__ __launch_bounds__(256, 2) void attn_flash_dkv_kernel(const AttArgs a,
             }
         }
         if (qt + 1 < ntiles && threadIdx.x < ATT_TILE) {     // buffer (qt+1)&1 was last read in iteration qt-1
-            lses[(qt + 1) & 1][threadIdx.x] = nl;
-            dels[(qt + 1) & 1][threadIdx.x] = nd;
+            const bool in = qn + (int)threadIdx.x < a.S;
+            lses[(qt + 1) & 1][threadIdx.x] = in ? nl * ATT_LOG2E : 1.0e30f;
+            dels[(qt + 1) & 1][threadIdx.x] = in ? nd : 0.f;
         }
     }
 #pragma unroll

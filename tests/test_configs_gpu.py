@@ -52,6 +52,30 @@ def test_flash_attention_s4097_all_heads(dev):
     assert (ctx.float().abs().sum(-1) > 0).all() and (dqkv.float().abs().sum(-1) > 0).all()
 
 
+def test_flash_attention_is_bitwise_reproducible_under_load(dev, monkeypatch):
+    """The tiled kernels keep the next K / V tile's LDS-DMA in flight while they work on this one; every query row's arithmetic is the same whatever
+    the rows-per-wave grouping, so with the whole chip busy (16 images x 12 heads at S = 4097) repeated launches and RB = 1 / 2 / 4 must agree BIT FOR BIT.
+    Round 4: a build whose transposed reads no longer made hipcc wait for the DMA read tiles that had not landed - context and LSE off by
+    rounding-size errors in a few workgroups, differently on every launch; the 1e-2 comparison against fp32 attention above never noticed."""
+    from mmgclip import kernels as K
+    B, S, heads = 16, 4097, 12
+    qkv = (torch.randn(B * S, 3 * heads * 64, generator=torch.Generator().manual_seed(16)) * 0.5).to(dev).to(BF)
+    dctx = torch.randn(B * S, heads * 64, generator=torch.Generator().manual_seed(17)).to(dev).to(BF)
+    ref = None
+    for rb in ("1", "2", "4", "4"):
+        monkeypatch.setenv("MMG_ATT_RB", rb)
+        ctx, lse = K.attention_fwd(qkv, None, B, S, heads)
+        dq = K.attention_bwd(qkv, None, ctx, lse, dctx, B, S, heads)
+        # (LSE order / the dK, dV grouping may depend on RB: compare those between equal settings only)
+        if ref is None:
+            ref = (ctx.clone(), {})
+        assert torch.equal(ctx, ref[0]), rb
+        if rb in ref[1]:
+            assert torch.equal(lse, ref[1][rb][0]) and torch.equal(dq, ref[1][rb][1]), rb
+        ref[1][rb] = (lse.clone(), dq.clone())
+    assert torch.isfinite(ctx.float()).all() and torch.isfinite(dq.float()).all()
+
+
 def test_attention_rows_per_wave_knob_is_validated(dev, monkeypatch):
     """MMG_ATT_RB outside {1, 2, 4} must not leave rows unwritten (it used to launch RB = 1 on a grid sized for the env value)."""
     from mmgclip import kernels as K

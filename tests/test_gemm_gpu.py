@@ -400,6 +400,24 @@ def test_tn_fp8_integer_exact_asymmetric(dev, monkeypatch, wide):
     assert torch.equal(cs.cpu(), a.sum(0))
 
 
+@pytest.mark.parametrize("kind,M,N1,N2", [("8bit", 262144, 512, 2048), ("8bit", 65536, 1024, 4096), ("bf16", 1048576, 384, 1536), ("bf16", 4194304, 96, 384)])
+def test_weight_gradient_gemms_are_integer_exact_at_full_size_under_load(dev, kind, M, N1, N2):
+    """BASELINE-size reductions on small-integer operands: every product and every fp32 partial sum is exact whatever the order of the atomics, so ONE
+    wrong operand byte anywhere shows up as an inequality.  These kernels read transposed fragments (inline-assembly ds_read_tr) while their LDS-DMA
+    ring is in flight - the property the tiled attention kernels got wrong for a build in round 4 (tools/tn_exact_check.py sweeps more shapes)."""
+    from mmgclip import linalg as L
+    g = torch.Generator().manual_seed(M % 1000 + N1)
+    a = torch.randint(-2, 3, (M, N1), generator=g).float().to(dev)
+    b = torch.randint(-1, 2, (M, N2), generator=g).float().to(dev)
+    ref, refc = a.t() @ b, a.sum(0)                          # exact: |sums| <= 2 M < 2^24
+    out, cs = torch.zeros(N1, N2, device=dev), torch.zeros(N1, device=dev)
+    if kind == "8bit":
+        L.gemm_tn_fp8_acc(a.to(torch.float8_e5m2).view(torch.uint8), b.to(torch.float8_e4m3fn).view(torch.uint8), out, colsum=cs)
+    else:
+        L.gemm_tn_acc(a.to(torch.bfloat16), b.to(torch.bfloat16), out, colsum=cs)
+    assert torch.equal(out, ref) and torch.equal(cs, refc)
+
+
 @pytest.mark.parametrize("wide", ["auto", "0", "1"])
 @pytest.mark.parametrize("M,N1,N2,e5", [(4096, 512, 2048, True), (33000, 2048, 512, True), (1000, 144, 80, True), (8192, 1024, 1024, False), (130, 128, 128, True),
                                         (20000, 384, 1536, True)])
