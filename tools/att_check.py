@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Run-to-run and grouping reproducibility of the tiled attention forward at ViT-B/16 1024^2 size (S = 4097, 12 heads) with the chip from lightly to
+fully loaded: a query row's arithmetic does not depend on rows-per-wave (MMG_ATT_RB), so every launch must give the SAME BITS.  Round 4: this is the
+tool that showed workgroups reading K / V tiles whose LDS-DMA had not landed (DESIGN.md "A wait the tiled attention kernels never had")."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mmg-clip_amd")]
