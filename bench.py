@@ -163,9 +163,10 @@ def _fp8_dtype(model):
     t = getattr(model, "image_encoder", None)
     t = getattr(t, "tower", t)
     c = getattr(t, "fp8_min_channels", 512)
-    if getattr(t, "fp8_bwd", False):
+    # (`fp8_bwd_now`: what the tower decided for the forwards of this run - the 8-bit backward only while its saved operands fit the device)
+    if getattr(t, "fp8_bwd", False) and getattr(t, "fp8_bwd_now", True):
         return f"fp8 (e4m3 forward + e5m2/e4m3 backward GEMMs in the C >= {c} ConvNeXt blocks; bf16 elsewhere)"
-    return f"bf16 (fp8 e4m3 forward GEMMs in the C >= {c} ConvNeXt blocks)"
+    return f"bf16 (fp8 e4m3 forward GEMMs in the C >= {c} ConvNeXt blocks; bf16 backward)"
 
 
 def _host_cores():
