@@ -306,7 +306,10 @@ def main():
         # peaks at 267 GiB
         # (checkpointing frees memory per micro-batch, so it keeps several of them)
         # ViT-B/16: 161.6 / 163.4 / 163.7 pairs/s at 64 / 128 / 256 (191 / 194 / 201 GiB)
-        args.micro_batch = 256 if (args.variant in ("tiny", "vit_b16") and not args.checkpoint) else 64
+        # round 4: checkpointed runs in micro-batches of 128 - the last micro-batch keeps its activations, so of n micro-batches n - 1 are recomputed:
+        # 1 of 2 instead of 3 of 4 (same box, 64 -> 128: C5 310 -> 336 pairs/s at 196 GiB, bf16 ConvNeXt-B 245 -> 264 at 239 GiB, ViT-B/16 142 -> 157 at 103 GiB,
+        # C2 693 -> 750 at 76 GiB)
+        args.micro_batch = 256 if (args.variant in ("tiny", "vit_b16") and not args.checkpoint) else (128 if args.checkpoint else 64)
 
     from mmgclip import distributed, linalg
     from mmgclip.dataset.synthetic import synthetic_batch
