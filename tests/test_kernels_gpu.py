@@ -432,6 +432,36 @@ def test_cnblock_backward_with_on_chip_weight_gradients(dev, M):
                        bufs["ln_dw"], bufs["ln_db"])
 
 
+def test_cnblock_bwdw_rows_beyond_2_31_bytes(dev):
+    """the kernel addresses row tiles by a scalar byte offset (tile * 12 288) that passes 2^31 at 11.2 M rows - the C2 step runs it at
+    16.8 M.  12 M rows made of 64 copies of one block of rows: every row's `dd` depends on that row alone, so the copies beyond 2^31 bytes must equal
+    the first block BIT FOR BIT (a wrapped offset reads or writes somewhere else), and the weight gradients must be 64 x those of one block."""
+    from mmgclip import kernels as K
+    C, P, REP = 96, 64 * 2930, 64                          # 187 520 rows per block, 12 001 280 rows = 2.30 GB per tensor
+    g_ = torch.Generator().manual_seed(5)
+    xd1 = (torch.randn(P, C, generator=g_) * 1.5 + 0.3).to(torch.bfloat16).to(dev)
+    dy1 = (0.5 * torch.randn(P, C, generator=g_)).to(torch.bfloat16).to(dev)
+    lnw, lnb = (1 + 0.2 * torch.randn(C, generator=g_)).to(dev), (0.1 * torch.randn(C, generator=g_)).to(dev)
+    w1, b1 = (torch.randn(4 * C, C, generator=g_) / C ** 0.5).to(dev), (0.1 * torch.randn(4 * C, generator=g_)).to(dev)
+    w2 = (torch.randn(C, 4 * C, generator=g_) / (4 * C) ** 0.5).to(dev)
+    ls = (0.3 + 0.7 * torch.rand(C, generator=g_)).to(dev)
+    packed, b1f = K.cnblock_bwdw_pack(w1, w2, lnw, lnb, ls, b1)
+    z = lambda *s: torch.zeros(*s, device=dev)   # noqa: E731
+
+    def run(xd, dy):
+        bufs = [z(4 * C, C), z(4 * C), z(C, 4 * C), z(C), z(C), z(C)]
+        dd = K.cnblock_bwdw(dy, xd, lnw, lnb, 1e-6, packed, b1f, *bufs)
+        torch.cuda.synchronize()
+        return dd, bufs
+    dd1, g1 = run(xd1, dy1)
+    xd, dy = xd1.repeat(REP, 1).contiguous(), dy1.repeat(REP, 1).contiguous()
+    assert xd.numel() * 2 > 2 ** 31 and K.cnblock_bwdw_supported(C, xd.shape[0])
+    dd, gN = run(xd, dy)
+    assert torch.equal(dd.view(REP, P, C), dd1.unsqueeze(0).expand(REP, P, C))
+    for a, b in zip(gN, g1):
+        assert float((a - REP * b).norm() / (REP * b).norm()) < 1e-4        # fp32 sums of 64 x as many terms, in another order
+
+
 # ---- fp8 (e4m3) operand producers --------------------------------------------------------------------------------------------
 def test_quantize_e4m3_matches_the_oracle_bytes(dev):
     """scale is a power of two, so src * scale is exact: bytes and scales must equal the oracle's bit for bit."""
