@@ -49,7 +49,8 @@ struct DwM {
     const bf16_t* x; const float* w; const float* bias; const bf16_t* add; bf16_t* y;
     int n, H, W, C, tiles_w, tiles_h, nt;
     unsigned m_img, m_tw;   // floor(2^32 / (tiles_w * tiles_h)), floor(2^32 / tiles_w)
-    int dbg;          // timing ablations only (MMG_DWM_DBG bit mask: 1 skip B, 2 skip D, 4 skip E, 8 skip F, 16 skip the global loads); results are then wrong
+    int dbg;          // (unused since the ablation mask became a build constant: -DDWM_DBG=mask, tools/build_ab_lib.sh dwm<mask> dwconv7_mfma -DDWM_DBG=<mask>:
+                      //  1 skip B, 2 skip D, 4 skip E, 8 skip F, 16 skip the global loads; results are then wrong)
 };
 
 // Workgroup barrier of the item loop: LDS traffic only.  __syncthreads() is fence + barrier and hipcc drains the vector-memory counter for it
@@ -67,7 +68,13 @@ __device__ __forceinline__ bf16x4 dm_tr(const char* p) { return __builtin_amdgcn
 // NW = waves per workgroup: 8 (4 channels each, 112 registers of Toeplitz fragments, two waves per SIMD) or 16 (2 channels each, 56 registers,
 // four waves per SIMD: the phases between two barriers are short dependent chains - LDS read -> MFMA chain -> LDS write - and with two waves
 // per SIMD their latencies lie open).
-template <bool FLIP, int NW>
+// ADD (residual-gradient operand) and the ablation mask are COMPILE-TIME: as run-time branches they left hipcc with registers that "may be" the
+// destination of a pending load on one of two merging paths, and it put `s_waitcnt vmcnt(0)` in front of the output stores of every item - of the
+// forward call too, which has no such operand - draining the two-items-ahead halo prefetch (round 4, ISA read).
+#ifndef DWM_DBG
+#define DWM_DBG 0
+#endif
+template <bool FLIP, int NW, bool ADD>
 __global__ __launch_bounds__(NW * 64, NW / 4) void dwconv7_mfma_kernel(const DwM p) {
     constexpr int DM_THREADS = NW * 64, CPW = DM_CB / NW, NIN = DM_CHUNKS / DM_THREADS, NOUT = 1024 / DM_THREADS;
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
@@ -148,14 +155,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dwconv7_mfma_kernel(const DwM
     // halo chunk it * 512 + tid -> pixel (hr, hc) of the 22 x 22 tile, channels 8 (tid & 3) ..
     const int part8 = (tid & 3) * 8;
     int h_off[NIN];                                               // element offset of the halo pixel from the tile's (y0 - 3, x0 - 3) corner
-    auto halo_rc = [&](int it, int& hr, int& hc) {             // (edge tiles only: recomputed, not kept)
-        const int pix = min((it * DM_THREADS + tid) >> 2, DM_NPIX - 1);     // (chunks past the tile: a valid pixel again, written to the unused tail)
+    // Thread id from the hardware, opaque to the optimiser (cnblock_bwdw.hip: bw_fresh_lane): what the EDGE tiles need per thread - halo row / column,
+    // output pixel - is re-derived from it at its use.  Derived from `tid` it is loop-invariant, hipcc hoisted it, ran out of the 128 registers of a
+    // 16-wave workgroup, and re-loaded it from scratch inside the item loop behind `s_waitcnt vmcnt(0)` - a drain of the halo prefetch per item.
+    auto fresh_tid = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return wave * 64 + l;
+    };
+    auto halo_rc = [&](int it, int t, int& hr, int& hc) {
+        const int pix = min((it * DM_THREADS + t) >> 2, DM_NPIX - 1);       // (chunks past the tile: a valid pixel again, written to the unused tail)
         hr = pix / DM_H; hc = pix - hr * DM_H;
     };
 #pragma unroll
     for (int it = 0; it < NIN; ++it) {
         int hr, hc;
-        halo_rc(it, hr, hc);
+        halo_rc(it, tid, hr, hc);
         h_off[it] = (hr * p.W + hc) * p.C + part8;
     }
     int o_off[NOUT];                                               // output chunk it * 512 + tid -> pixel (row, xx) of the 16 x 16 tile
@@ -164,40 +179,54 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dwconv7_mfma_kernel(const DwM
         const int pix = (it * DM_THREADS + tid) >> 2;
         o_off[it] = ((pix >> 4) * p.W + (pix & 15)) * p.C + part8;
     }
-    auto request = [&](uint4 (&set)[NIN], int s) {
+    // Every load of this kernel is UNCONDITIONAL and its result is first touched where it is consumed (round 4, second pass over this file): a
+    // load under a per-lane condition, or a value zeroed right behind its load, is a use at the end of that branch - hipcc waited there with
+    // vmcnt(0), i.e. for the whole two-items-ahead prefetch, in every edge tile (23 % of a 256 x 256 map) and, through the residual operand of
+    // the data-gradient call, in every item.  Out-of-image halo pixels: clamped address now, zero at DEPOSIT time from a mask kept with the set.
+    auto request = [&](uint4 (&set)[NIN], unsigned& inmask, int s) {
         int img, y0, x0;
         origin(s, img, y0, x0);
         const bf16_t* img_base = p.x + (size_t)img * p.H * p.W * p.C + c0;
+        long el[NIN];
+        unsigned m = 0xffffffffu;
         if (y0 >= 3 && x0 >= 3 && y0 + DM_T + 3 <= p.H && x0 + DM_T + 3 <= p.W) {          // (uniform) the halo lies inside the image
-            const bf16_t* corner = img_base + ((size_t)(y0 - 3) * p.W + (x0 - 3)) * p.C;
+            const long corner = ((long)(y0 - 3) * p.W + (x0 - 3)) * p.C;
 #pragma unroll
-            for (int it = 0; it < NIN; ++it) set[it] = *reinterpret_cast<const uint4*>(corner + h_off[it]);
+            for (int it = 0; it < NIN; ++it) el[it] = corner + h_off[it];
         } else {
+            m = 0;
+            const int ft = fresh_tid();
 #pragma unroll
             for (int it = 0; it < NIN; ++it) {
                 int hr, hc;
-                halo_rc(it, hr, hc);
+                halo_rc(it, ft, hr, hc);
                 const int gy = y0 - 3 + hr, gx = x0 - 3 + hc;
                 const bool in = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
                 const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-                uint4 v = *reinterpret_cast<const uint4*>(img_base + ((size_t)cy * p.W + cx) * p.C + part8);
-                if (!in) v = make_uint4(0, 0, 0, 0);            // pixels outside the image: zeros, decided here (the deposit is unconditional)
-                set[it] = v;
+                el[it] = ((long)cy * p.W + cx) * p.C + (ft & 3) * 8;
+                m |= (in ? 1u : 0u) << it;
             }
         }
+#pragma unroll
+        for (int it = 0; it < NIN; ++it) set[it] = *reinterpret_cast<const uint4*>(img_base + el[it]);
+        inmask = m;
     };
     char* dep_base = smem + DM_OFF_IN + tid * 16;
-    auto deposit = [&](const uint4 (&set)[NIN]) {              // registers -> NHWC LDS tile
+    auto deposit = [&](const uint4 (&set)[NIN], unsigned inmask) {              // registers -> NHWC LDS tile (pixels outside the image: zeros)
 #pragma unroll
-        for (int it = 0; it < NIN; ++it) *reinterpret_cast<uint4*>(dep_base + it * (DM_THREADS * 16)) = set[it];
+        for (int it = 0; it < NIN; ++it) {
+            uint4 v = set[it];
+            if (!((inmask >> it) & 1u)) v = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(dep_base + it * (DM_THREADS * 16)) = v;
+        }
     };
 
     uint4 preA[NIN], preB[NIN];
 #pragma unroll
     for (int it = 0; it < NIN; ++it) { preA[it] = make_uint4(0, 0, 0, 0); preB[it] = make_uint4(0, 0, 0, 0); }
-    const bool has_add = p.add != nullptr;
-    if (first < items) request(preA, first);
-    if (first + step < items) request(preB, first + step);
+    unsigned inA = 0xffffffffu, inB = 0xffffffffu;
+    if (first < items) request(preA, inA, first);
+    if (first + step < items) request(preB, inB, first + step);
 
     char* planar = smem + DM_OFF_PLANAR;
     // phase B: wave w moves halo rows w, w + NW, (w + 2 NW) (< 22): per row 12 units (6 groups of 4 columns x 2 channel halves) = 3 wave instructions
@@ -215,26 +244,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dwconv7_mfma_kernel(const DwM
     // phase F
     const char* f_src = smem + DM_OFF_OUT + (tid >> 2) * DM_OPIX + (tid & 3) * 16;                                    // + it * (threads / 4) * 80
 
-    auto one_item = [&](int item, uint4 (&pre)[NIN]) {
+    auto one_item = [&](int item, uint4 (&pre)[NIN], unsigned& inm) {
         int img, y0, x0;
         origin(item, img, y0, x0);
         const size_t tile_el = ((size_t)img * p.H + y0) * p.W * p.C + (size_t)x0 * p.C + c0;      // (uniform) element offset of the tile's first pixel
         const bool full = y0 + DM_T <= p.H && x0 + DM_T <= p.W;                                     // (uniform) no output pixel outside the image
         // ================= A: this item's halo tile: registers -> LDS; the same registers then take item + 2 ============================
-        deposit(pre);
-        if (item + 2 * step < items && !(p.dbg & 16)) request(pre, item + 2 * step);
+        deposit(pre, inm);
+        // residual-gradient operand of the output pass (consumed in F, four barriers away) - requested BEFORE the halo tile of item + 2: the
+        // vector-memory counter retires in order, so a wait for these registers in F also waits for every load issued before them.  With the
+        // halo request first (round 4, first version) phase F drained the two-items-ahead prefetch every item: the data-gradient call ran 49 %
+        // slower than the forward for 25 % more bytes.
         uint4 addv[NOUT];
-        if (has_add) {                                            // residual-gradient operand of the output pass (consumed in F, four barriers away)
+        if constexpr (ADD) {
 #pragma unroll
-            for (int it = 0; it < NOUT; ++it) {
-                const int pix = (it * DM_THREADS + tid) >> 2;
-                const bool ok = full || (y0 + (pix >> 4) < p.H && x0 + (pix & 15) < p.W);
-                addv[it] = ok ? *reinterpret_cast<const uint4*>(p.add + tile_el + o_off[it]) : make_uint4(0, 0, 0, 0);
+            for (int it = 0; it < NOUT; ++it) {              // (pixels past the image edge: a clamped address, never stored)
+                size_t el = tile_el + o_off[it];
+                if (!full) {                                   // (uniform)
+                    const int ft = fresh_tid(), pix = (it * DM_THREADS + ft) >> 2;
+                    const int py = min(y0 + (pix >> 4), p.H - 1), px = min(x0 + (pix & 15), p.W - 1);
+                    el = ((size_t)img * p.H + py) * p.W * p.C + (size_t)px * p.C + c0 + (ft & 3) * 8;
+                }
+                addv[it] = *reinterpret_cast<const uint4*>(p.add + el);
             }
         }
+        if (item + 2 * step < items && !(DWM_DBG & 16)) request(pre, inm, item + 2 * step);
         dm_barrier();
         // ================= B: NHWC halo tile -> channel planes (the LDS transposes: 4 pixels x 16 channels per 16 lanes) ================
-        if (!(p.dbg & 1)) {
+        if constexpr (!(DWM_DBG & 1)) {
 #pragma unroll
             for (int r = 0; r < BR; ++r) {
                 if (r + 1 < BR || wave < DM_H - (BR - 1) * NW) {  // (uniform: the last row group exists for the first waves only; EXEC stays full inside)
@@ -251,22 +288,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dwconv7_mfma_kernel(const DwM
         // Two channels at a time: their 14 fragments are requested together and the two accumulation chains alternate (a 16x16x32 MFMA
         // depends on its predecessor's accumulator).  A channel's outputs go back into the plane they were computed from: only this wave
         // touches its four planes in this phase and its LDS accesses stay in program order, so the writes follow the reads.
-        if (!(p.dbg & 2)) {
+        if constexpr (!(DWM_DBG & 2)) {
 #pragma unroll
             for (int cp = 0; cp < CPW / 2; ++cp) {
                 char* pl0 = d_plane + (2 * cp) * DM_PLANE;
-                bf16x8 a0[7], a1[7];
-#pragma unroll
-                for (int ky = 0; ky < 7; ++ky) {
-                    a0[ky] = *reinterpret_cast<const bf16x8*>(pl0 + d_rd + ky * DM_ROWB);
-                    a1[ky] = *reinterpret_cast<const bf16x8*>(pl0 + DM_PLANE + d_rd + ky * DM_ROWB);
-                }
+                // (fragments in two batches, ky 0-3 and 4-6: all 14 at once are 56 registers beside the 56 of T - with 16 waves (128 registers) hipcc
+                //  spilled 26 and re-loaded per-item offsets from scratch INSIDE the item loop, each reload behind `s_waitcnt vmcnt(0)` = a drain of
+                //  the two-items-ahead halo prefetch; round 4, ISA read)
                 f32x4 acc0 = f32x4{bia[2 * cp], bia[2 * cp], bia[2 * cp], bia[2 * cp]};
                 f32x4 acc1 = f32x4{bia[2 * cp + 1], bia[2 * cp + 1], bia[2 * cp + 1], bia[2 * cp + 1]};
 #pragma unroll
-                for (int ky = 0; ky < 7; ++ky) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T[2 * cp][ky], a0[ky], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T[2 * cp + 1][ky], a1[ky], acc1, 0, 0, 0);
+                for (int kb = 0; kb < 7; kb += 4) {
+                    bf16x8 a0[4], a1[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (kb + k < 7) {
+                            a0[k] = *reinterpret_cast<const bf16x8*>(pl0 + d_rd + (kb + k) * DM_ROWB);
+                            a1[k] = *reinterpret_cast<const bf16x8*>(pl0 + DM_PLANE + d_rd + (kb + k) * DM_ROWB);
+                        }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (kb + k < 7) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T[2 * cp][kb + k], a0[k], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T[2 * cp + 1][kb + k], a1[k], acc1, 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 *reinterpret_cast<uint2*>(pl0 + d_wr) = make_uint2(pack2bf(acc0[0], acc0[1]), pack2bf(acc0[2], acc0[3]));
@@ -276,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dwconv7_mfma_kernel(const DwM
         }
         dm_barrier();
         // ================= E: output planes -> NHWC tile =================================================================================
-        if (!(p.dbg & 4)) {
+        if constexpr (!(DWM_DBG & 4)) {
 #pragma unroll
             for (int it = 0; it < ER; ++it) {
                 const bf16x4 lo = dm_tr(e_src + it * DM_OROWB), hi = dm_tr(e_src + it * DM_OROWB + 4 * DM_PLANE);
@@ -286,13 +332,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dwconv7_mfma_kernel(const DwM
         dm_barrier();
         // ================= F: 16-byte rows of the NHWC tile -> HBM (+ residual-gradient operand) =========================================
         // (no barrier after it: the next item's E, which re-writes the output tile, lies behind three more barriers)
-        if (!(p.dbg & 8)) {
+        if constexpr (!(DWM_DBG & 8)) {
 #pragma unroll
             for (int it = 0; it < NOUT; ++it) {
                 const int pix = (it * DM_THREADS + tid) >> 2;
                 if (full || (y0 + (pix >> 4) < p.H && x0 + (pix & 15) < p.W)) {
                     uint4 v = *reinterpret_cast<const uint4*>(f_src + it * ((DM_THREADS / 4) * DM_OPIX));
-                    if (has_add) {
+                    if constexpr (ADD) {
                         const uint4 a = addv[it];
                         v.x = pack2bf(bf2f_lo(v.x) + bf2f_lo(a.x), bf2f_hi(v.x) + bf2f_hi(a.x));
                         v.y = pack2bf(bf2f_lo(v.y) + bf2f_lo(a.y), bf2f_hi(v.y) + bf2f_hi(a.y));
@@ -305,8 +351,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void dwconv7_mfma_kernel(const DwM
         }
     };
     for (int item = first; item < items; item += 2 * step) {
-        one_item(item, preA);
-        if (item + step < items) one_item(item + step, preB);
+        one_item(item, preA, inA);
+        if (item + step < items) one_item(item + step, preB, inB);
     }
 }
 
@@ -318,7 +364,7 @@ MMG_API int mmg_dwconv7_nhwc_mfma(const void* x, const float* w, const float* bi
     p.m_img = (unsigned)((1ULL << 32) / (unsigned long long)(p.tiles_w * p.tiles_h > 1 ? p.tiles_w * p.tiles_h : 2));
     p.m_tw = (unsigned)((1ULL << 32) / (unsigned long long)(p.tiles_w > 1 ? p.tiles_w : 2));
     p.nt = (size_t)n * H * W * C * 2 >= ((size_t)256 << 20);
-    p.dbg = getenv("MMG_DWM_DBG") ? atoi(getenv("MMG_DWM_DBG")) : 0;
+    p.dbg = DWM_DBG;
     const long items = (long)n * p.tiles_w * p.tiles_h;
     const int slabs = C / DM_CB;
     MMG_CHECK_ARG(items < (1L << 30), "mmg_dwconv7_nhwc_mfma: too many tiles");
@@ -332,13 +378,15 @@ MMG_API int mmg_dwconv7_nhwc_mfma(const void* x, const float* w, const float* bi
     const int grid = 8 * per_xcd;
     const int nw = getenv("MMG_DWM_WAVES") ? atoi(getenv("MMG_DWM_WAVES")) : 16;
     MMG_NOTE_KERNEL("dwconv7_mfma_kernel<%s, %d>", flip ? "true" : "false", nw == 8 ? 8 : 16);
-#define DM_LAUNCH(FL, W_)                                                                                     \
+#define DM_LAUNCH(FL, W_, AD)                                                                                 \
     do {                                                                                                      \
-        mmg_allow_lds(dwconv7_mfma_kernel<FL, W_>, DM_LDS);                                                   \
-        hipLaunchKernelGGL((dwconv7_mfma_kernel<FL, W_>), dim3(grid), dim3(W_ * 64), DM_LDS, stream, p);      \
+        mmg_allow_lds(dwconv7_mfma_kernel<FL, W_, AD>, DM_LDS);                                               \
+        hipLaunchKernelGGL((dwconv7_mfma_kernel<FL, W_, AD>), dim3(grid), dim3(W_ * 64), DM_LDS, stream, p);  \
     } while (0)
-    if (flip) { if (nw == 8) DM_LAUNCH(true, 8); else DM_LAUNCH(true, 16); }
-    else      { if (nw == 8) DM_LAUNCH(false, 8); else DM_LAUNCH(false, 16); }
+#define DM_LAUNCH_W(FL, AD) do { if (nw == 8) DM_LAUNCH(FL, 8, AD); else DM_LAUNCH(FL, 16, AD); } while (0)
+    if (flip) { if (add) DM_LAUNCH_W(true, true); else DM_LAUNCH_W(true, false); }
+    else      { if (add) DM_LAUNCH_W(false, true); else DM_LAUNCH_W(false, false); }
+#undef DM_LAUNCH_W
 #undef DM_LAUNCH
     MMG_LAUNCH_CHECK("mmg_dwconv7_nhwc_mfma");
     return 0;

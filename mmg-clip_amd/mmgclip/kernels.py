@@ -175,12 +175,13 @@ def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0)
 
 
 def dwconv_mfma_pays(n, H, W, C, flip):
-    """Where the matrix-core kernel beat the VALU one in the same-process A/B at the benchmark's batch (tools/dwm_scale.py, profiles/
-    r04_dwconv_mfma_scale.txt, n = 256): few channel slabs (its persistent grid deals 32 workgroups per XCD group over C / 32 slabs: at C = 384 /
-    768 a quarter of them idle); the data gradient (+ residual operand) only up to C = 128 (ConvNeXt-B stage 1, tools/dwm_scale_b.py: -9 %; at
-    C = 256 / 512 / 1024 the VALU kernels win both directions).  The rule reads the MAP size and the width only, never the
-    image count: a tower must take the same kernel whatever micro-batch it is run in (taps are rounded to bf16 here, kept fp32 there)."""
-    return H * W >= 96 * 96 and (C <= 128 if flip else C <= 192)
+    """Where the matrix-core kernel beats the VALU one in the same-process A/B (tools/dwm_scale.py at n = 256, tools/dwm_scale_b.py at n = 64;
+    profiles/r04_dwconv_mfma_scale2.txt, _scale_b2.txt - after the kernel's loads were made unconditional and its spills removed: -25 % / -23 % at
+    96 channels of 256 x 256, -15 % / -19 % at 192 of 128 x 128, -36 % / -25 % at ConvNeXt-B's 128, -5 % / -14 % at its 256): large maps with few
+    channel slabs, both directions.  On the 64 x 64 / 32 x 32 maps of stages 3 - 4 (tiles of 16 x 16: the halo is 1.9 x the tile, few items per CU) the
+    two are at parity or the VALU kernels win.  The rule reads the MAP size and the width only, never the image count: a tower must take the same
+    kernel whatever micro-batch it is run in (taps are rounded to bf16 here, kept fp32 there)."""
+    return H * W >= 96 * 96 and C <= 256
 
 
 def dwconv7(x, w49, bias, n, H, W, C, add=None, flip=False, out=None):
