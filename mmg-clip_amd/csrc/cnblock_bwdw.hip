@@ -318,13 +318,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
         bw_barrier();                                                                                    // A
         BWP_T(pr_a1);
         BWP_ADD(1, pr_p0, pr_a0); BWP_ADD(2, pr_a0, pr_a1);
-        // next tile's rows: requested now, consumed at its P0
-        if (st_on && tile + (int)gridDim.x < a.ntiles) {
-            const int st_off_n = st_off_f();
+        // next tile's rows, consumed at its P0.  Launch 1 requests them now (it stages them in the middle of this tile's P1).  Launch 2 requests them
+        // AFTER its P1 (round 4, ISA read): its step loop waits for weight fragments requested during the loop, the vector-memory counter retires in
+        // order, and hipcc's `s_waitcnt vmcnt(0)` in front of the second step's products therefore also waited for these three HBM loads - one
+        // exposed memory latency per tile; behind the loop they have P2 + P3 to land, and P1 has 12 registers more.
+        auto request_rows = [&]() {
+            if (st_on && tile + (int)gridDim.x < a.ntiles) {
+                const int st_off_n = st_off_f();
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off_n + 64 * ks, bw_soff((unsigned)tile + gridDim.x, R * C * 2), 0);
-        }
+                for (int ks = 0; ks < KS; ++ks)
+                    pre[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_row, st_off_n + 64 * ks, bw_soff((unsigned)tile + gridDim.x, R * C * 2), 0);
+            }
+        };
+        if (!DX) request_rows();
 
         // ================= P1: this wave's 48 hidden units over the 64 rows ==========================================================
         // Six steps (row-tile pair rp, hidden tile ht), rp outer.  Every operand is requested well before its use and lives in ONE
@@ -483,6 +489,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void cnblock_bwdw_kernel(const BwA
                 for (int ht = 0; ht < HT; ++ht) bacc[ht] += dbsum[ht];
             }
         }
+        if (DX) request_rows();
         BWP_T(pr_b0);
         if (DX) bw_barrier();                                                                            // B: the dh image is complete (launch 1: nothing to wait for - the next tile stages into the other image pair)
         BWP_T(pr_b1);
