@@ -397,15 +397,24 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
     float* s_dg = s_b1 + 4 * C;                                  // LayerNorm weight / bias gradient of this workgroup
     float* s_db = s_dg + C;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (uniform: the addresses below split into a scalar base + one 32-bit lane offset)
     const int li = lane & 15, lg = lane >> 4;
     char* lds_wave = smem + (tid & ~63) * 16;
-    const char* wsrc = reinterpret_cast<const char*>(p.wt) + tid * 16;
+    // Addresses inside the chunk loop are "uniform 64-bit base (scalar registers) + per-thread 32-bit offset" (round 4, ISA read of the C = 192
+    // instantiation at 256 VGPRs): as per-lane 64-bit pointers hipcc kept one register pair per DMA piece and per stored row tile, spilled them, and
+    // re-loaded each from scratch behind `s_waitcnt vmcnt(0)` - every one of the nine DMA instructions of a chunk waited for the previous one to
+    // LAND, and every pair of g / dh stores for all earlier stores to complete: the kernel that "was bound by its HBM stores" was serialised.
+    // -> buffer instructions: descriptor + scalar offset + ONE 32-bit lane offset (as cnblock_bwdw.hip does), so there is nothing 64-bit per lane to keep.
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, NCH * CHUNK, 0x27000);
+    const int toff = tid * 16;
     auto stage = [&](int buf, int ch) {
-        const char* s = wsrc + (size_t)ch * CHUNK;
 #pragma unroll
-        for (int it = 0; it < LOADS; ++it) mlp_glds16(s + it * (MLP_THREADS * 16), lds_wave + buf * CHUNK + it * (MLP_THREADS * 16));
+        for (int it = 0; it < LOADS; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds_wave + buf * CHUNK + it * (MLP_THREADS * 16)), 16, toff,
+                                                 ch * CHUNK + it * (MLP_THREADS * 16), 0, 0);
     };
+    const int soff = (li * (4 * C) + 8 * lg) * 2;      // byte offset of this lane's 16-byte piece inside a 16-row x 4C row block
     if ((int)blockIdx.x < p.ntiles) stage(0, 0);
     for (int i = tid; i < C; i += MLP_THREADS) { s_lnw[i] = p.ln_w[i]; s_lnb[i] = p.ln_b[i]; s_dg[i] = 0.f; s_db[i] = 0.f; }
     for (int i = tid; i < 4 * C; i += MLP_THREADS) s_b1[i] = p.b1[i];
@@ -413,6 +422,11 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const long row0 = (long)tile * MLP_BM + wave * (16 * MT) + li;
+        // g / dh: one descriptor per tensor over THIS WAVE's 16 MT rows of the tile; rows past M lie outside its range and their stores are dropped
+        const long wrow0 = (long)tile * MLP_BM + wave * (16 * MT);
+        const long wrows = p.M - wrow0 < 0 ? 0 : (p.M - wrow0 < 16 * MT ? p.M - wrow0 : 16 * MT);
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g + wrow0 * (4 * C)), 0, (int)(wrows * (4 * C) * 2), 0x27000);
+        const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dh + wrow0 * (4 * C)), 0, (int)(wrows * (4 * C) * 2), 0x27000);
         bf16x8 xf[RECOMP ? MT : 1][RECOMP ? KS1 : 1], dyf[MT][KS1];
         float row_mean[MT], row_rstd[MT];
 #pragma unroll
@@ -473,7 +487,12 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
             for (int ct = 0; ct < CT; ++ct) dxacc[mi][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int ch = 0; ch < NCH; ++ch) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // this chunk's weights have landed.  From the second chunk of a tile on, everything this wave issued after that DMA is the previous
+            // chunk's 2 MT NSUB buffer stores of g / dh (always issued: rows past M are dropped by the descriptor's range check, not by a
+            // branch) - the counter retires in order, so they may stay in flight instead of being waited for chunk by chunk
+            constexpr int NST_CH = 2 * MT * NSUB;
+            if (RECOMP && ch > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST_CH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (ch + 1 < NCH) stage((ch + 1) & 1, ch + 1);
             else if (tile + (int)gridDim.x < p.ntiles) stage(0, 0);
@@ -531,10 +550,15 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                         dp[2 * tt] = pack2bf(d[0], d[1]); dp[2 * tt + 1] = pack2bf(d[2], d[3]);
                     }
                     dhf[mi] = __builtin_bit_cast(bf16x8, (u32x4_t{dp[0], dp[1], dp[2], dp[3]}));
-                    const long row = row0 + 16 * mi;
-                    if (row < p.M) {
-                        store16_stream(p.g + row * (4 * C) + n0, make_uint4(gp[0], gp[1], gp[2], gp[3]), p.nt);
-                        store16_stream(p.dh + row * (4 * C) + n0, make_uint4(dp[0], dp[1], dp[2], dp[3]), p.nt);
+                    {
+                        const int vo = soff + mi * (16 * 4 * C * 2), so = (ch * NC + sub * 32) * 2;
+                        if (p.nt) {            // (uniform) streamed past L2: aux bit 1 = nt
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{gp[0], gp[1], gp[2], gp[3]}, rs_g, vo, so, 2);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{dp[0], dp[1], dp[2], dp[3]}, rs_dh, vo, so, 2);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{gp[0], gp[1], gp[2], gp[3]}, rs_g, vo, so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{dp[0], dp[1], dp[2], dp[3]}, rs_dh, vo, so, 0);
+                        }
                     }
                 }
 #pragma unroll
