@@ -313,6 +313,12 @@ __global__ __launch_bounds__(RW ? RW * 64 : MlpCfg<C>::THREADS, RW ? RW / 4 : Ml
         }
 
         // ---- y = x + gamma * (acc + b2) -----------------------------------------------------------------------------------
+        // (lane id from the hardware here, opaque to the optimiser: derived from `lane`, the per-lane base pointers "tensor + 16 lg bytes" are
+        //  loop-invariant, hipcc hoisted them out of the tile loop, spilled them at 168 registers (resident form) and re-loaded them in every tile
+        //  behind `s_waitcnt vmcnt(0)` - in front of the residual loads and again in front of the stores; round 4, ISA read)
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int lg_e = lane_e >> 4;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
@@ -320,10 +326,10 @@ __global__ __launch_bounds__(RW ? RW * 64 : MlpCfg<C>::THREADS, RW ? RW / 4 : Ml
                 // c-tile pair (2j, 2j+1) of this lane = columns 32j + 8 lg .. +7
                 uint4 rv[CT / 2];
 #pragma unroll
-                for (int j = 0; j < CT / 2; ++j) rv[j] = *reinterpret_cast<const uint4*>(p.res + row * C + 32 * j + 8 * lg);
+                for (int j = 0; j < CT / 2; ++j) rv[j] = *reinterpret_cast<const uint4*>(p.res + row * C + 32 * j + 8 * lg_e);
 #pragma unroll
                 for (int j = 0; j < CT / 2; ++j) {
-                    const int c8 = 32 * j + 8 * lg;
+                    const int c8 = 32 * j + 8 * lg_e;
                     const unsigned rw[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
                     unsigned o[4];
 #pragma unroll
