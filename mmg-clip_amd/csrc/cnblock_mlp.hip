@@ -435,6 +435,11 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
         const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dh + wrow0 * (4 * C)), 0, (int)(wrows * (4 * C) * 2), 0x27000);
         bf16x8 xf[RECOMP ? MT : 1][RECOMP ? KS1 : 1], dyf[MT][KS1];
         float row_mean[MT], row_rstd[MT];
+        // (lane group from the hardware for the global addresses of the tile prologue / epilogue: derived from `lane`, the per-lane bases "tensor +
+        //  16 lg bytes" are loop-invariant 64-bit values that hipcc hoists, spills at 256 registers and re-loads per tile behind vmcnt(0))
+        int lane_t;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+        const int lg_t = lane_t >> 4;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const long row = row0 + 16 * mi;
@@ -442,8 +447,8 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
             uint4 raw[KS1];
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                raw[ks] = *reinterpret_cast<const uint4*>(p.xd + rr * C + 32 * ks + 8 * lg);
-                const uint4 dv = *reinterpret_cast<const uint4*>(p.dy + rr * C + 32 * ks + 8 * lg);
+                raw[ks] = *reinterpret_cast<const uint4*>(p.xd + rr * C + 32 * ks + 8 * lg_t);
+                const uint4 dv = *reinterpret_cast<const uint4*>(p.dy + rr * C + 32 * ks + 8 * lg_t);
                 dyf[mi][ks] = __builtin_bit_cast(bf16x8, (u32x4_t{dv.x, dv.y, dv.z, dv.w}));
             }
             float v[KS1][8];
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                     o[e] = pack2bf(fmaf((v[ks][2 * e] - mean) * rstd, g[2 * e], b[2 * e]),
                                    fmaf((v[ks][2 * e + 1] - mean) * rstd, g[2 * e + 1], b[2 * e + 1]));
                 if (RECOMP) xf[RECOMP ? mi : 0][RECOMP ? ks : 0] = __builtin_bit_cast(bf16x8, (u32x4_t{o[0], o[1], o[2], o[3]}));
-                if (row < p.M) *reinterpret_cast<uint4*>(p.xln + row * C + 32 * ks + 8 * lg) = make_uint4(o[0], o[1], o[2], o[3]);
+                if (row < p.M) *reinterpret_cast<uint4*>(p.xln + row * C + 32 * ks + 8 * lg_t) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
 
@@ -576,6 +581,9 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                 }
             }
         }
+        int lane_x;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_x));
+        const int lg_x = lane_x >> 4;
         if (!LNB) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
 #pragma unroll
                     for (int j = 0; j < CT / 2; ++j) {
                         const f32x4 a = dxacc[mi][2 * j], b = dxacc[mi][2 * j + 1];
-                        *reinterpret_cast<uint4*>(p.dxln + row * C + 32 * j + 8 * lg) =
+                        *reinterpret_cast<uint4*>(p.dxln + row * C + 32 * j + 8 * lg_x) =
                             make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3]));
                     }
                 }
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
                 const long row = row0 + 16 * mi;
                 const long rr = row < p.M ? row : p.M - 1;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) xv[mi][ct] = *reinterpret_cast<const uint2*>(p.xd + rr * C + 32 * (ct >> 1) + 8 * lg + 4 * (ct & 1));
+                for (int ct = 0; ct < CT; ++ct) xv[mi][ct] = *reinterpret_cast<const uint2*>(p.xd + rr * C + 32 * (ct >> 1) + 8 * lg_x + 4 * (ct & 1));
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(MlpCfg<C>::THREADS, MlpCfg<C>::WGS_BWD) void cnbloc
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const int cc = 32 * (ct >> 1) + 8 * lg + 4 * (ct & 1);       // this lane's 4 columns of tile ct
+                const int cc = 32 * (ct >> 1) + 8 * lg_x + 4 * (ct & 1);     // this lane's 4 columns of tile ct
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(s_lnw + cc);
                 float cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
